@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ray-steps/sec of the OMEGA 60-beam sweep (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one full pass of the hot path over the workload: zero the deposition grid, tabulate the
+plasma node tables, trace this rank's share of the ray bundles of all 60 beams, all-reduce the grid
+(RCCL) when N > 1.  Inputs are resident in HBM before the timed region.  The workload is fixed as N
+grows (60 beams sharded N ways) -> "scaling": "strong".  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BYTES_PER_RAY_STEP = 128      # 8 fp64 gathers + 8 fp64 atomic-add payloads
+HBM_PEAK = 8.0e12             # MI355X_MICROARCH.md: HBM3E spec B/s (6.29e12 measured copy rate)
+
+
+def cpu_baseline(n, r, ne, te, bn):
+    """The serial CPU ray loop (oracle/cbet_oracle.c, 1 thread) on a bounded sample of the same
+    workload: beam 0 of the n^3 sweep (~1/60 of the ray-steps)."""
+    from oracle import cbet_oracle as O
+    cfg = O.default_config(n)
+    t0 = time.perf_counter()
+    _, steps = O.trace(cfg, bn, r, ne, te, beam_lo=0, beam_hi=1, nthreads=1)
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "ray-steps/s", "cores": 1, "kind": "port",
+            "sample": "beam 0 of the %d^3 60-beam s83177 sweep: %d ray-steps in %.1f s, "
+                      "1 thread, gcc -O2 -ffp-contract=off" % (n, steps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=256, help="grid nodes per axis (BASELINE config 3: 256)")
+    ap.add_argument("--variant", type=int, default=0, help="cbet_params.kernel_variant (0 = default)")
+    ap.add_argument("--window", type=int, default=0, help="cbet_params.lds_window_log2 (0 = default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from cbet_raytracing_3d_amd import api
+    from cbet_raytracing_3d_amd.tracer import RayTracer, allreduce_grid, shard_of_rank
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    n = args.n
+    r, ne, te = api.load_s83177()
+    bn = api.omega60_beam_norm()
+    p = api.default_params(n, kernel_variant=args.variant, lds_window_log2=args.window)
+    tr = RayTracer(p, r, ne, te, beam_norm=bn)
+    edep = tr.new_grid()
+    si, sc = shard_of_rank(rank, world)
+    d = tr.derived
+    stream = torch.cuda.current_stream().cuda_stream
+    launch_p = tr.params.copy(beam_lo=0, beam_hi=60, shard_index=si, shard_count=sc)
+
+    ev = []   # HIP events bracketing the trace kernel on its stream
+
+    def step(timed):
+        edep.zero_()
+        api.tabulate_plasma(tr.ctx, launch_p, tr.d_te, tr.d_r, tr.d_ne, stream)
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        api.trace_nodes(0, d.nindices, None, None, edep, tr.d_bbeam_norm, tr.d_beam_norm, tr.d_pow_r,
+                        tr.d_phase_r, d.xconst, d.yconst, d.zconst, launch_p, tr.ctx, stream)
+        if timed:
+            e1.record()
+            ev.append((e0, e1))
+        allreduce_grid(edep)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    tr.counters(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    cnt = tr.counters(reset=True)
+    tot = torch.tensor([float(cnt.ray_steps), float(cnt.global_atomics), elapsed,
+                        sum(a.elapsed_time(b) for a, b in ev) * 1e-3],
+                       dtype=torch.float64, device="cuda")
+    tmax = tot.clone()
+    if world > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    steps_total = tot[0].item()                      # ray-steps over all ranks and all K steps
+    elapsed_max = tmax[2].item()
+    kernel_s_rank = tmax[3].item() / max(1, args.steps)   # slowest rank's average trace-kernel time
+    value = steps_total / elapsed_max
+
+    if rank == 0:
+        steps_per_launch = steps_total / args.steps / world   # ray-steps one launch processes (avg rank)
+        achieved = steps_per_launch * BYTES_PER_RAY_STEP / kernel_s_rank
+        out = {
+            "metric": "ray-steps/sec, OMEGA 60-beam %d^3 sweep" % n,
+            "value": value, "unit": "ray-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed_max / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic (OMEGA-60 port table + s83177 ne/Te profile, deterministic)",
+            "config": {"workload": "omega60_%dcube_s83177_absorption" % n, "grid": n, "beams": 60,
+                       "ray_steps_per_pass": steps_total / args.steps,
+                       "rays_per_pass": 60 * int(d.nlive_rays), "kernel_variant": args.variant,
+                       "sharding": "ray bundles interleaved over %d rank(s), all-reduce of the "
+                                   "(n+2)^3 fp64 grid per pass" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+                         "kernel": "k_trace", "kernel_ms": 1e3 * kernel_s_rank,
+                         "bytes_per_ray_step": BYTES_PER_RAY_STEP,
+                         "global_atomics_per_ray_step": tot[1].item() / max(1.0, steps_total)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, r, ne, te, bn)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,330 @@
+"""ctypes binding of the C ABI in include/cbet_mi355x.h.
+
+This is plumbing over libcbet_mi355x.so (hand-written HIP for gfx950): every function here calls
+straight into the library and raises CbetError when the library reports a failure.  There is no
+CPU fallback -- if the shared library is missing, importing this module raises.
+
+Names mirror the reference's interface for the path (file:line into /root/reference):
+    safeGPUAlloc / moveToAndFromGPU   multi_gpu.cuh:6-7
+    launch_ray_XYZ                    launch_ray_XZ.cu:117-121 (launch site main.cu:171-174)
+    ray_tracing                       rayTracing(), main.cu:96-232
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libcbet_mi355x.so")
+DATA_DIR = os.path.join(_PKG, "data")
+
+OK, EINVAL, EHIP, ENOMEM, ENODEVICE, ECOMM = 0, -1, -2, -3, -4, -5
+NPHASE = 2001
+KERNEL_DEFAULT, KERNEL_GLOBAL_ATOMICS, KERNEL_LDS_COMBINE = 0, 1, 2
+
+
+class CbetError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("cbet error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Params(C.Structure):
+    """cbet_params (def.cuh:33-131 as run-time fields)."""
+    _fields_ = [
+        ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int),
+        ("xmin", C.c_double), ("xmax", C.c_double),
+        ("ymin", C.c_double), ("ymax", C.c_double),
+        ("zmin", C.c_double), ("zmax", C.c_double),
+        ("nbeams", C.c_int), ("rays_per_zone", C.c_int),
+        ("courant_mult", C.c_double),
+        ("absorption", C.c_int), ("nprofile", C.c_int),
+        ("max_threads", C.c_int), ("threads_per_block", C.c_int),
+        ("ngpus", C.c_int),
+        ("beam_lo", C.c_int), ("beam_hi", C.c_int),
+        ("shard_index", C.c_int), ("shard_count", C.c_int),
+        ("kernel_variant", C.c_int), ("lds_window_log2", C.c_int),
+        ("reserved", C.c_int * 6),
+    ]
+
+    def copy(self, **overrides):
+        q = Params()
+        C.memmove(C.byref(q), C.byref(self), C.sizeof(Params))
+        for k, v in overrides.items():
+            setattr(q, k, v)
+        return q
+
+
+class Derived(C.Structure):
+    """cbet_derived (def.cuh / main.cu:156-161 derived constants)."""
+    _fields_ = [
+        ("dx", C.c_double), ("dy", C.c_double), ("dz", C.c_double), ("dt", C.c_double),
+        ("nt", C.c_int), ("zones_spanned", C.c_int),
+        ("nrays_x", C.c_int), ("nrays_y", C.c_int), ("nrays", C.c_int),
+        ("omega", C.c_double), ("ncrit", C.c_double), ("uray_mult", C.c_double),
+        ("xconst", C.c_double), ("yconst", C.c_double), ("zconst", C.c_double),
+        ("threads_per_beam", C.c_long), ("nindices", C.c_int), ("grid_y", C.c_int),
+        ("edep_size", C.c_long), ("ntraced_ids", C.c_long), ("nlive_rays", C.c_long),
+    ]
+
+
+class Counters(C.Structure):
+    _fields_ = [
+        ("ray_steps", C.c_ulonglong), ("rays_traced", C.c_ulonglong),
+        ("global_atomics", C.c_ulonglong), ("lds_evictions", C.c_ulonglong),
+        ("reserved", C.c_ulonglong * 4),
+    ]
+
+
+# Every symbol include/cbet_mi355x.h declares; tests check the library exports all of them.
+EXPORTS = [
+    "cbet_last_error", "cbet_version", "cbet_params_default", "cbet_derive",
+    "cbet_live_ray_list", "cbet_omega60_beam_norm", "cbet_host_power_table", "cbet_host_beam_trig", "cbet_read_profile",
+    "cbet_safeGPUAlloc", "cbet_moveToAndFromGPU", "cbet_gpuFree",
+    "cbet_context_create", "cbet_context_destroy", "cbet_context_counters", "cbet_context_tables",
+    "cbet_launch_ray_XYZ", "cbet_tabulate_plasma", "cbet_trace_nodes", "cbet_ray_tracing",
+]
+
+_lib = None
+
+
+def lib():
+    """Loads libcbet_mi355x.so; raises (loudly) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: build it with `python -m cbet_raytracing_3d_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)
+    L.cbet_last_error.restype = C.c_char_p
+    L.cbet_version.restype = C.c_char_p
+    L.cbet_params_default.argtypes = [C.POINTER(Params), C.c_int]
+    L.cbet_derive.argtypes = [C.POINTER(Params), C.POINTER(Derived)]
+    L.cbet_live_ray_list.argtypes = [C.POINTER(Params), ip, C.c_long, C.POINTER(C.c_long)]
+    L.cbet_omega60_beam_norm.restype = dp
+    L.cbet_host_power_table.argtypes = [dp, dp]
+    L.cbet_host_beam_trig.argtypes = [dp, C.c_int, dp]
+    L.cbet_read_profile.argtypes = [C.c_char_p, C.c_int, dp, dp]
+    L.cbet_safeGPUAlloc.argtypes = [C.POINTER(vp), C.c_size_t, C.c_int]
+    L.cbet_moveToAndFromGPU.argtypes = [vp, vp, C.c_size_t, C.c_int]
+    L.cbet_gpuFree.argtypes = [vp, C.c_int]
+    L.cbet_context_create.argtypes = [C.POINTER(vp), C.POINTER(Params), C.c_int]
+    L.cbet_context_destroy.argtypes = [vp]
+    L.cbet_context_counters.argtypes = [vp, vp, C.POINTER(Counters), C.c_int]
+    L.cbet_context_tables.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.cbet_launch_ray_XYZ.argtypes = [C.c_int, C.c_uint, vp, vp, vp, vp, vp, vp, vp, vp,
+                                      C.c_double, C.c_double, C.c_double, C.POINTER(Params), vp, vp]
+    L.cbet_tabulate_plasma.argtypes = [vp, C.POINTER(Params), vp, vp, vp, vp]
+    L.cbet_trace_nodes.argtypes = [C.c_int, C.c_uint, vp, vp, vp, vp, vp, vp, vp,
+                                   C.c_double, C.c_double, C.c_double, C.POINTER(Params), vp, vp]
+    L.cbet_ray_tracing.argtypes = [dp, dp, dp, dp, C.POINTER(Params), dp, ip, C.c_int, dp,
+                                   C.POINTER(Counters)]
+    for name in EXPORTS:
+        getattr(L, name)  # AttributeError here = the library is older than the header
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != OK:
+        raise CbetError(rc, lib().cbet_last_error().decode("utf-8", "replace"))
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _addr(x):
+    """Device/host address of a torch tensor, numpy array, ctypes pointer or int (None -> NULL)."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if hasattr(x, "data_ptr"):
+        return x.data_ptr()
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    if isinstance(x, C.c_void_p):
+        return x.value
+    raise TypeError("cannot take the address of %r" % type(x))
+
+
+# ---- configuration -----------------------------------------------------------------------------
+def version():
+    return lib().cbet_version().decode()
+
+
+def default_params(n=100, **overrides):
+    p = Params()
+    _check(lib().cbet_params_default(C.byref(p), n))
+    for k, v in overrides.items():
+        setattr(p, k, v)
+    return p
+
+
+def derive(p):
+    d = Derived()
+    _check(lib().cbet_derive(C.byref(p), C.byref(d)))
+    return d
+
+
+def live_ray_list(p):
+    """Launch list in kernel order: 64 consecutive entries form one bundle, -1 marks a hole
+    (see cbet_live_ray_list in the header)."""
+    n = C.c_long()
+    _check(lib().cbet_live_ray_list(C.byref(p), None, 0, C.byref(n)))
+    out = np.zeros(n.value, dtype=np.int32)
+    _check(lib().cbet_live_ray_list(C.byref(p), out.ctypes.data_as(C.POINTER(C.c_int)), n.value,
+                                    C.byref(n)))
+    return out
+
+
+def shard_items(p, nbeams_local, shard_index, shard_count):
+    """Host-side statement of the kernel's work split: the (beam_local, thread-ray id) pairs that
+    shard `shard_index` of `shard_count` traces (bundle g -> shard g % shard_count)."""
+    live = live_ray_list(p)
+    bpb = (len(live) + 63) // 64
+    beams, ids = [], []
+    for g in range(shard_index, nbeams_local * bpb, max(1, shard_count)):
+        b, k = divmod(g, bpb)
+        chunk = live[64 * k: 64 * k + 64]
+        chunk = chunk[chunk >= 0]
+        beams.append(np.full(len(chunk), b, dtype=np.int32))
+        ids.append(chunk)
+    if not ids:
+        return np.zeros(0, np.int32), np.zeros(0, np.int32)
+    return np.concatenate(beams), np.concatenate(ids)
+
+
+def omega60_beam_norm():
+    ptr = lib().cbet_omega60_beam_norm()
+    return np.ctypeslib.as_array(ptr, shape=(60, 3)).copy()
+
+
+def host_power_table():
+    phase, powr = np.zeros(NPHASE), np.zeros(NPHASE)
+    _check(lib().cbet_host_power_table(_dptr(phase), _dptr(powr)))
+    return phase, powr
+
+
+def host_beam_trig(beam_norm):
+    bn = np.ascontiguousarray(beam_norm, dtype=np.float64).reshape(-1, 3)
+    out = np.zeros((bn.shape[0], 4))
+    _check(lib().cbet_host_beam_trig(_dptr(bn), bn.shape[0], _dptr(out)))
+    return out
+
+
+def read_profile(path, nprofile=443):
+    r, v = np.zeros(nprofile), np.zeros(nprofile)
+    _check(lib().cbet_read_profile(os.fsencode(path), nprofile, _dptr(r), _dptr(v)))
+    return r, v
+
+
+def load_s83177(nprofile=443):
+    """(r, ne, te) of the s83177 shot at 1.5 ns, first `nprofile` rows (main.cu:249-260:
+    the Te file is read first, then the ne file, whose radii overwrite the first's)."""
+    _, te = read_profile(os.path.join(DATA_DIR, "s83177_te.txt"), nprofile)
+    r, ne = read_profile(os.path.join(DATA_DIR, "s83177_ne.txt"), nprofile)
+    return r, ne, te
+
+
+# ---- multi_gpu.cuh helpers ---------------------------------------------------------------------
+def safeGPUAlloc(size, gpu):
+    """multi_gpu.cpp:3-28.  Returns the device address (int)."""
+    out = C.c_void_p()
+    _check(lib().cbet_safeGPUAlloc(C.byref(out), size, gpu))
+    return out.value
+
+
+def moveToAndFromGPU(dst, src, size, gpu):
+    """multi_gpu.cpp:44-59.  dst/src: addresses, numpy arrays or torch tensors."""
+    _check(lib().cbet_moveToAndFromGPU(_addr(dst), _addr(src), size, gpu))
+
+
+def gpuFree(ptr, gpu):
+    _check(lib().cbet_gpuFree(_addr(ptr), gpu))
+
+
+# ---- workspace ---------------------------------------------------------------------------------
+class Context:
+    """cbet_context: per-device workspace (node tables, live-ray list, counters)."""
+
+    def __init__(self, params, gpu=0):
+        self._h = C.c_void_p()
+        self.gpu = gpu
+        _check(lib().cbet_context_create(C.byref(self._h), C.byref(params), gpu))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def counters(self, stream=None, reset=False):
+        c = Counters()
+        _check(lib().cbet_context_counters(self._h, _addr(stream), C.byref(c), 1 if reset else 0))
+        return c
+
+    def tables(self):
+        a, b = C.c_void_p(), C.c_void_p()
+        _check(lib().cbet_context_tables(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def close(self):
+        if self._h:
+            lib().cbet_context_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- the hot path ------------------------------------------------------------------------------
+def launch_ray_XYZ(b, nindices, te_data_g, r_data_g, ne_data_g, edep, bbeam_norm, beam_norm, pow_r,
+                   phase_r, xconst, yconst, zconst, params, ctx=None, stream=None):
+    """launch_ray_XZ.cu:117-121 argument for argument, plus params / workspace / stream.
+    Pointer arguments are device addresses (ints) or torch tensors."""
+    _check(lib().cbet_launch_ray_XYZ(
+        b, nindices, _addr(te_data_g), _addr(r_data_g), _addr(ne_data_g), _addr(edep),
+        _addr(bbeam_norm), _addr(beam_norm), _addr(pow_r), _addr(phase_r), xconst, yconst, zconst,
+        C.byref(params), ctx.handle if ctx is not None else None, _addr(stream)))
+
+
+def tabulate_plasma(ctx, params, te_data_g, r_data_g, ne_data_g, stream=None):
+    _check(lib().cbet_tabulate_plasma(ctx.handle, C.byref(params), _addr(te_data_g),
+                                      _addr(r_data_g), _addr(ne_data_g), _addr(stream)))
+
+
+def trace_nodes(b, nindices, ne3d, kappa3d, edep, bbeam_norm, beam_norm, pow_r, phase_r, xconst,
+                yconst, zconst, params, ctx, stream=None):
+    _check(lib().cbet_trace_nodes(
+        b, nindices, _addr(ne3d), _addr(kappa3d), _addr(edep), _addr(bbeam_norm), _addr(beam_norm),
+        _addr(pow_r), _addr(phase_r), xconst, yconst, zconst, C.byref(params), ctx.handle,
+        _addr(stream)))
+
+
+def ray_tracing(te_profile, r_profile, ne_profile, edep, params, beam_norm=None, gpus=None, ngpu=1):
+    """rayTracing() (main.cu:96-232): host profiles in, host `edep` (numpy, (nx+2,ny+2,nz+2))
+    ADDED into.  Returns (timers{init,tracing,combining,total}, Counters)."""
+    te = np.ascontiguousarray(te_profile, dtype=np.float64)
+    r = np.ascontiguousarray(r_profile, dtype=np.float64)
+    ne = np.ascontiguousarray(ne_profile, dtype=np.float64)
+    if not (isinstance(edep, np.ndarray) and edep.dtype == np.float64 and edep.flags.c_contiguous):
+        raise TypeError("edep must be a C-contiguous float64 numpy array")
+    bn = None
+    if beam_norm is not None:
+        bn = np.ascontiguousarray(beam_norm, dtype=np.float64)
+    garr = None
+    if gpus is not None:
+        garr = (C.c_int * len(gpus))(*gpus)
+        ngpu = len(gpus)
+    timers = np.zeros(4)
+    cnt = Counters()
+    _check(lib().cbet_ray_tracing(_dptr(te), _dptr(r), _dptr(ne), _dptr(edep), C.byref(params),
+                                  _dptr(bn) if bn is not None else None, garr, ngpu, _dptr(timers),
+                                  C.byref(cnt)))
+    return dict(zip(("init", "tracing", "combining", "total"), timers.tolist())), cnt

@@ -1,0 +1,55 @@
+"""Builds libcbet_mi355x.so (HIP kernels for gfx950 + the C ABI) in-tree with hipcc.
+
+hipcc cross-compiles gfx950 without a GPU, so this runs in the build container; the resulting
+.so travels to the GPU box with the source snapshot.  `python -m cbet_raytracing_3d_amd.build`.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB_DIR = os.path.join(PKG, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libcbet_mi355x.so")
+SOURCES = ["cbet_kernels.hip", "cbet_abi.cpp", "cbet_host.cpp"]
+HEADERS = [os.path.join(CSRC, "cbet_device.h"), os.path.join(ROOT, "include", "cbet_mi355x.h"),
+           os.path.join(ROOT, "include", "cbet_omega_beams.h")]
+
+# -ffp-contract=off: a ray's fp64 arithmetic must be the reference's operation sequence (no fused
+# multiply-add), see cbet_kernels.hip.  No -ffast-math: fp64 div/sqrt stay correctly rounded.
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared",
+         "-Wall", "-Wno-unused-result"]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found (need ROCm to build the gfx950 library)")
+    return exe
+
+
+def is_stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    built = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > built for d in deps)
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    if not force and not is_stale():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc()] + FLAGS + list(extra_flags) + [
+        "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+        "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lrccl"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

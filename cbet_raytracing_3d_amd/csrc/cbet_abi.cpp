@@ -1,0 +1,556 @@
+// cbet_abi.cpp -- host side of the C ABI in include/cbet_mi355x.h: parameter derivation, the
+// per-device workspace, the multi_gpu.cuh helper counterparts and the launch entry points.
+// Citations are into /root/reference/.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "cbet_device.h"
+#include "cbet_mi355x.h"
+#include "cbet_omega_beams.h"
+
+namespace cbet {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define CBET_HIP(call)                                                                          \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return ::cbet::fail(CBET_EHIP, "%s failed: %s", #call, hipGetErrorString(e_));      \
+    } while (0)
+
+// Restores the caller's current device on scope exit (moveToAndFromGPU's save/restore,
+// multi_gpu.cpp:50-57).
+struct DeviceGuard {
+    int saved = -1;
+    DeviceGuard() { (void)hipGetDevice(&saved); }
+    ~DeviceGuard() { if (saved >= 0) (void)hipSetDevice(saved); }
+};
+
+static int validate(const cbet_params *p)
+{
+    if (!p) return fail(CBET_EINVAL, "params is NULL");
+    if (p->nx < 3 || p->ny < 3 || p->nz < 3) return fail(CBET_EINVAL, "grid needs >= 3 nodes per axis");
+    if ((long)(p->nx + 2) * (p->ny + 2) * (p->nz + 2) >= 0x7FFFFFFFL)
+        return fail(CBET_EINVAL, "grid too large for 32-bit node tags ((n+2)^3 must be < 2^31)");
+    if (!(p->xmax > p->xmin) || !(p->ymax > p->ymin) || !(p->zmax > p->zmin))
+        return fail(CBET_EINVAL, "empty extent");
+    if (p->nbeams < 1) return fail(CBET_EINVAL, "nbeams < 1");
+    if (p->rays_per_zone < 1 || p->rays_per_zone > 64) return fail(CBET_EINVAL, "rays_per_zone out of range");
+    if (!(p->courant_mult > 0)) return fail(CBET_EINVAL, "courant_mult <= 0");
+    if (p->nprofile < 2 || p->nprofile > 4096) return fail(CBET_EINVAL, "nprofile out of range [2,4096]");
+    if (p->max_threads < 1 || p->threads_per_block < 1) return fail(CBET_EINVAL, "bad launch-shape rule");
+    if (p->shard_count > 1 && (p->shard_index < 0 || p->shard_index >= p->shard_count))
+        return fail(CBET_EINVAL, "shard_index outside [0, shard_count)");
+    return CBET_OK;
+}
+
+// def.cuh:33-131 and main.cu:156-161, evaluated operation by operation as written there.
+static void derive_core(const cbet_params *p, cbet_derived *d)
+{
+    d->dx = (p->xmax - p->xmin) / (p->nx - 1);
+    d->dy = (p->ymax - p->ymin) / (p->ny - 1);
+    d->dz = (p->zmax - p->zmin) / (p->nz - 1);
+    d->dt = p->courant_mult * std::min(d->dx, d->dz) / kC;           // def.cuh:81
+    d->nt = (int)((1 / p->courant_mult) * p->nx * 2.0);               // def.cuh:83-84
+    d->zones_spanned = (int)std::ceil((kBeamMax - kBeamMin) / d->dx); // launch_ray_XZ.cu:69
+    d->nrays_x = (int)(p->rays_per_zone * std::ceil((kBeamMax - kBeamMin) / d->dx));
+    d->nrays_y = (int)(p->rays_per_zone * std::ceil((kBeamMax - kBeamMin) / d->dy));
+    d->nrays = d->nrays_x * d->nrays_y;
+    const double freq = kC / kLambda;                                 // def.cuh:67
+    d->omega = 2 * M_PI * freq;                                       // def.cuh:68
+    d->ncrit = 1e-6 * (d->omega * d->omega) * kMe * kE0 / (kEc * kEc);// def.cuh:69
+    d->uray_mult = kIntensity * (p->courant_mult) / (double(p->rays_per_zone * p->rays_per_zone));
+    const double grad_const = std::pow(kC, 2) / (2.0 * d->ncrit) * d->dt * 0.5;  // main.cu:156
+    d->xconst = grad_const / d->dx;
+    d->yconst = grad_const / d->dy;
+    d->zconst = grad_const / d->dz;
+    const long total = (long)d->nrays * p->nbeams;                    // def.cuh:125-129
+    const long nthreads = std::min<long>(p->max_threads, total);
+    d->threads_per_beam = nthreads / p->nbeams;
+    d->nindices = (int)std::ceil(d->nrays / (float)(d->threads_per_beam));
+    d->grid_y = (int)(d->threads_per_beam / p->threads_per_block);    // main.cu:161
+    d->edep_size = ((long)p->nx + 2) * ((long)p->ny + 2) * ((long)p->nz + 2);
+    d->ntraced_ids = 0;
+    d->nlive_rays = 0;
+}
+
+// launch_ray_XZ.cu:125,155-158 with main.cu:161's truncated grid.y: is thread-ray id visited?
+static bool id_is_traced(const cbet_params *p, const cbet_derived *d, int nindices, long id)
+{
+    const long start = id % d->threads_per_beam, pass = id / d->threads_per_beam;
+    return start < (long)d->grid_y * p->threads_per_block && pass < nindices;
+}
+
+// launch_ray_XZ.cu:76-92 : launch coordinate by repeated addition, then + d/2.
+static std::vector<double> launch_axis(int count, int denom_count, double half_cell)
+{
+    std::vector<double> t(count);
+    double acc = kBeamMin;
+    for (int i = 0; i < count; ++i) {
+        t[i] = acc + half_cell;
+        acc += (kBeamMax - kBeamMin) / (denom_count - 1);
+    }
+    return t;
+}
+
+static unsigned morton2(unsigned x, unsigned y)
+{
+    auto spread = [](unsigned v) {
+        v &= 0xFFFF;
+        v = (v | (v << 8)) & 0x00FF00FF;
+        v = (v | (v << 4)) & 0x0F0F0F0F;
+        v = (v | (v << 2)) & 0x33333333;
+        v = (v | (v << 1)) & 0x55555555;
+        return v;
+    };
+    return spread(x) | (spread(y) << 1);
+}
+
+// The beam-independent launch list.  The beam cross-section (nrays_x x nrays_y rays,
+// launch_ray_XZ.cu:69-74) is cut into 8x8-ray patches visited along a Morton curve; each patch is
+// one ray bundle = one wavefront, lane = 8*row + column.  An entry is the thread-ray id the
+// reference would give that ray (the inverse of :70-74's permutation), or -1 for a hole: a ray
+// outside the ray grid, one the reference launch shape never visits (:155-158, main.cu:161), or one
+// that fails init()'s beam-radius test (:94,114).  Patches with no live ray are dropped.
+static void build_live_list(const cbet_params *p, const cbet_derived *d, int nindices,
+                            const std::vector<double> &xl, const std::vector<double> &yl,
+                            std::vector<int> &slots, long &ntraced, long &nlive)
+{
+    const int rpz = p->rays_per_zone, rpz2 = rpz * rpz;
+    const int zx = d->zones_spanned;
+    const int px = (d->nrays_x + 7) / 8, py = (d->nrays_y + 7) / 8;
+    std::vector<std::pair<unsigned, int>> order;
+    order.reserve((size_t)px * py);
+    for (int y = 0; y < py; ++y)
+        for (int x = 0; x < px; ++x) order.emplace_back(morton2(x, y), y * px + x);
+    std::sort(order.begin(), order.end());
+    slots.clear();
+    ntraced = 0;
+    nlive = 0;
+    // ids the launch shape visits, counted once over the whole ray grid
+    for (long id = 0; id < d->nrays; ++id)
+        if (id_is_traced(p, d, nindices, id)) ++ntraced;
+    for (auto &o : order) {
+        const int bx = (o.second % px) * 8, by = (o.second / px) * 8;
+        int patch[kWave];
+        int alive = 0;
+        for (int l = 0; l < kWave; ++l) {
+            const int rx = bx + (l & 7), ry = by + (l >> 3);
+            patch[l] = -1;
+            if (rx >= d->nrays_x || ry >= d->nrays_y) continue;
+            const long tile = (long)(ry / rpz) * zx + rx / rpz;           // inverse of :72-73
+            const long id = tile * rpz2 + (ry % rpz) * rpz + rx % rpz;    // inverse of :70-71
+            if (id >= d->nrays || !id_is_traced(p, d, nindices, id)) continue;
+            const double ref = std::sqrt(xl[rx] * xl[rx] + yl[ry] * yl[ry]);
+            if (!(ref <= kBeamMax)) continue;
+            patch[l] = (int)id;
+            ++alive;
+        }
+        if (!alive) continue;
+        slots.insert(slots.end(), patch, patch + kWave);
+        nlive += alive;
+    }
+}
+
+}  // namespace cbet
+
+using namespace cbet;
+
+struct cbet_context {
+    int gpu = -1;
+    cbet_params p{};
+    cbet_derived d{};
+    double *ne3d = nullptr, *kap3d = nullptr;
+    double *xlaunch = nullptr, *ylaunch = nullptr;
+    int *live = nullptr;
+    int nlive = 0;  // launch-list slots (64 per bundle, holes included)
+    unsigned long long *counters = nullptr;
+};
+
+extern "C" {
+
+const char *cbet_last_error(void) { return g_err; }
+const char *cbet_version(void) { return "cbet-mi355x 0.1 (gfx950, hip)"; }
+
+int cbet_params_default(cbet_params *p, int n)
+{
+    if (!p) return fail(CBET_EINVAL, "params is NULL");
+    std::memset(p, 0, sizeof *p);
+    p->nx = p->ny = p->nz = n;
+    p->xmin = p->ymin = p->zmin = -0.13;
+    p->xmax = p->ymax = p->zmax = 0.13;
+    p->nbeams = 60;
+    p->rays_per_zone = 4;
+    p->courant_mult = 0.5;
+    p->absorption = 1;
+    p->nprofile = 443;
+    p->max_threads = 120000000;
+    p->threads_per_block = 256;
+    p->ngpus = 1;
+    p->shard_index = 0;
+    p->shard_count = 1;
+    p->kernel_variant = CBET_KERNEL_DEFAULT;
+    return CBET_OK;
+}
+
+int cbet_derive(const cbet_params *p, cbet_derived *d)
+{
+    if (int rc = validate(p)) return rc;
+    if (!d) return fail(CBET_EINVAL, "derived is NULL");
+    derive_core(p, d);
+    if (d->threads_per_beam < 1) return fail(CBET_EINVAL, "no threads per beam");
+    auto xl = launch_axis(d->nrays_x, d->nrays_x, d->dx / 2);
+    auto yl = launch_axis(d->nrays_y, d->nrays_y, d->dy / 2);
+    std::vector<int> live;
+    long ntraced = 0, nlive = 0;
+    build_live_list(p, d, d->nindices, xl, yl, live, ntraced, nlive);
+    d->ntraced_ids = ntraced;
+    d->nlive_rays = nlive;
+    return CBET_OK;
+}
+
+int cbet_live_ray_list(const cbet_params *p, int *out, long cap, long *count)
+{
+    if (int rc = validate(p)) return rc;
+    if (!count) return fail(CBET_EINVAL, "count is NULL");
+    cbet_derived d;
+    derive_core(p, &d);
+    if (d.threads_per_beam < 1) return fail(CBET_EINVAL, "no threads per beam");
+    auto xl = launch_axis(d.nrays_x, d.nrays_x, d.dx / 2);
+    auto yl = launch_axis(d.nrays_y, d.nrays_y, d.dy / 2);
+    std::vector<int> live;
+    long ntraced = 0, nlive = 0;
+    build_live_list(p, &d, d.nindices, xl, yl, live, ntraced, nlive);
+    *count = (long)live.size();
+    if (out)
+        for (long i = 0; i < std::min<long>(cap, (long)live.size()); ++i) out[i] = live[i];
+    return CBET_OK;
+}
+
+const double *cbet_omega60_beam_norm(void) { return &cbet_omega60_ports[0][0]; }
+
+int cbet_host_power_table(double *phase_r, double *pow_r)
+{
+    if (!phase_r || !pow_r) return fail(CBET_EINVAL, "NULL table");
+    // main.cu:24-32 span(0.0, 0.1, 2001): running sum
+    const double step = (0.1 - 0.0) / (CBET_NPHASE - 1);
+    double acc = 0.0;
+    for (unsigned i = 0; i < CBET_NPHASE; ++i) {
+        phase_r[i] = acc;
+        acc += step;
+    }
+    for (unsigned i = 0; i < CBET_NPHASE; ++i)  // main.cu:108-110
+        pow_r[i] = std::exp(-1 * std::pow(std::pow((phase_r[i] / kSigma), 2), (5.0 / 2.0)));
+    return CBET_OK;
+}
+
+int cbet_host_beam_trig(const double *beam_norm, int nbeams, double *bbeam_norm)
+{
+    if (!beam_norm || !bbeam_norm || nbeams < 1) return fail(CBET_EINVAL, "bad beam table");
+    for (int b = 0; b < nbeams; ++b) {  // main.cu:122-129
+        const double theta1 = std::acos(beam_norm[3 * b + 2]);
+        const double theta2 = std::atan2(beam_norm[3 * b + 1] * kFocal, beam_norm[3 * b + 0] * kFocal);
+        bbeam_norm[4 * b] = std::cos(theta1);
+        bbeam_norm[4 * b + 1] = std::sin(theta1);
+        bbeam_norm[4 * b + 2] = std::cos(theta2);
+        bbeam_norm[4 * b + 3] = std::sin(theta2);
+    }
+    return CBET_OK;
+}
+
+int cbet_read_profile(const char *path, int nprofile, double *r, double *v)
+{
+    if (!path || !r || !v || nprofile < 1) return fail(CBET_EINVAL, "bad profile arguments");
+    FILE *f = std::fopen(path, "r");
+    if (!f) return fail(CBET_EINVAL, "cannot open profile file %s", path);
+    for (int i = 0; i < nprofile; ++i) {  // main.cu:251-252: exactly nr rows
+        if (std::fscanf(f, "%lf %lf", &r[i], &v[i]) != 2) {
+            std::fclose(f);
+            return fail(CBET_EINVAL, "profile file %s has fewer than %d rows", path, nprofile);
+        }
+    }
+    std::fclose(f);
+    return CBET_OK;
+}
+
+// ---- multi_gpu.cpp:3-28 ---------------------------------------------------------------------
+int cbet_safeGPUAlloc(void **dst, size_t size, int gpu)
+{
+    if (!dst) return fail(CBET_EINVAL, "dst is NULL");
+    hipError_t e = hipSetDevice(gpu);  // stays current, as in the reference (:7)
+    if (e != hipSuccess) return fail(CBET_ENODEVICE, "hipSetDevice(%d): %s", gpu, hipGetErrorString(e));
+    size_t free_b = 0, total_b = 0;
+    e = hipMemGetInfo(&free_b, &total_b);
+    if (e != hipSuccess) return fail(CBET_EHIP, "Error encountered during hipMemGetInfo: %s", hipGetErrorString(e));
+    if (free_b < size) return fail(CBET_ENOMEM, "GPU: %d is out of memory", gpu);
+    e = hipMalloc(dst, size);
+    if (e != hipSuccess) return fail(CBET_EHIP, "Error encountered during hipMalloc: %s", hipGetErrorString(e));
+    return CBET_OK;
+}
+
+// ---- multi_gpu.cpp:44-59 --------------------------------------------------------------------
+int cbet_moveToAndFromGPU(void *dst, void *src, size_t size, int gpu)
+{
+    if (gpu == -1) return fail(CBET_ENODEVICE, "Attempting to move data that has not been assigned a GPU");
+    if (size && (!dst || !src)) return fail(CBET_EINVAL, "NULL pointer");
+    DeviceGuard guard;
+    hipError_t e = hipSetDevice(gpu);
+    if (e != hipSuccess) return fail(CBET_ENODEVICE, "hipSetDevice(%d): %s", gpu, hipGetErrorString(e));
+    e = hipMemcpy(dst, src, size, hipMemcpyDefault);
+    if (e != hipSuccess) return fail(CBET_EHIP, "Error encountered during hipMemcpy: %s", hipGetErrorString(e));
+    return CBET_OK;
+}
+
+int cbet_gpuFree(void *ptr, int gpu)
+{
+    DeviceGuard guard;
+    hipError_t e = hipSetDevice(gpu);
+    if (e != hipSuccess) return fail(CBET_ENODEVICE, "hipSetDevice(%d): %s", gpu, hipGetErrorString(e));
+    CBET_HIP(hipFree(ptr));
+    return CBET_OK;
+}
+
+// ---- workspace --------------------------------------------------------------------------------
+int cbet_context_destroy(cbet_context *ctx)
+{
+    if (!ctx) return CBET_OK;
+    DeviceGuard guard;
+    (void)hipSetDevice(ctx->gpu);
+    (void)hipFree(ctx->ne3d);
+    (void)hipFree(ctx->kap3d);
+    (void)hipFree(ctx->xlaunch);
+    (void)hipFree(ctx->ylaunch);
+    (void)hipFree(ctx->live);
+    (void)hipFree(ctx->counters);
+    delete ctx;
+    return CBET_OK;
+}
+
+int cbet_context_create(cbet_context **out, const cbet_params *p, int gpu)
+{
+    if (!out) return fail(CBET_EINVAL, "ctx out-pointer is NULL");
+    *out = nullptr;
+    if (int rc = validate(p)) return rc;
+    cbet_derived d;
+    derive_core(p, &d);
+    if (d.threads_per_beam < 1) return fail(CBET_EINVAL, "no threads per beam");
+    auto xl = launch_axis(d.nrays_x, d.nrays_x, d.dx / 2);
+    auto yl = launch_axis(d.nrays_y, d.nrays_y, d.dy / 2);
+    std::vector<int> live;
+    long ntraced = 0, nlive = 0;
+    build_live_list(p, &d, d.nindices, xl, yl, live, ntraced, nlive);
+    d.ntraced_ids = ntraced;
+    d.nlive_rays = nlive;
+
+    DeviceGuard guard;
+    hipError_t e = hipSetDevice(gpu);
+    if (e != hipSuccess) return fail(CBET_ENODEVICE, "hipSetDevice(%d): %s", gpu, hipGetErrorString(e));
+    cbet_context *ctx = new cbet_context;
+    ctx->gpu = gpu;
+    ctx->p = *p;
+    ctx->d = d;
+    ctx->nlive = (int)live.size();
+    const size_t nodes = (size_t)p->nx * p->ny * p->nz;
+    auto bail = [&](hipError_t err, const char *what) {
+        cbet_context_destroy(ctx);
+        return fail(err == hipErrorOutOfMemory ? CBET_ENOMEM : CBET_EHIP, "%s: %s", what, hipGetErrorString(err));
+    };
+    if ((e = hipMalloc((void **)&ctx->ne3d, nodes * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(ne3d)");
+    if ((e = hipMalloc((void **)&ctx->kap3d, nodes * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(kappa3d)");
+    if ((e = hipMalloc((void **)&ctx->xlaunch, xl.size() * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(xlaunch)");
+    if ((e = hipMalloc((void **)&ctx->ylaunch, yl.size() * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(ylaunch)");
+    if ((e = hipMalloc((void **)&ctx->live, std::max<size_t>(1, live.size()) * sizeof(int))) != hipSuccess) return bail(e, "hipMalloc(live)");
+    if ((e = hipMalloc((void **)&ctx->counters, kCntSlots * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(counters)");
+    if ((e = hipMemcpy(ctx->xlaunch, xl.data(), xl.size() * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(xlaunch)");
+    if ((e = hipMemcpy(ctx->ylaunch, yl.data(), yl.size() * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(ylaunch)");
+    if (!live.empty() &&
+        (e = hipMemcpy(ctx->live, live.data(), live.size() * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess)
+        return bail(e, "hipMemcpy(live)");
+    if ((e = hipMemset(ctx->counters, 0, kCntSlots * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMemset(counters)");
+    *out = ctx;
+    return CBET_OK;
+}
+
+int cbet_context_counters(cbet_context *ctx, void *stream, cbet_counters *out, int reset)
+{
+    if (!ctx || !out) return fail(CBET_EINVAL, "NULL context/counters");
+    DeviceGuard guard;
+    CBET_HIP(hipSetDevice(ctx->gpu));
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long h[kCntSlots];
+    CBET_HIP(hipMemcpyAsync(h, ctx->counters, sizeof h, hipMemcpyDeviceToHost, s));
+    if (reset) CBET_HIP(hipMemsetAsync(ctx->counters, 0, sizeof h, s));
+    CBET_HIP(hipStreamSynchronize(s));
+    std::memset(out, 0, sizeof *out);
+    out->ray_steps = h[kCntSteps];
+    out->rays_traced = h[kCntRays];
+    out->global_atomics = h[kCntGlobalAtomics];
+    out->lds_evictions = h[kCntEvictions];
+    return CBET_OK;
+}
+
+int cbet_context_tables(cbet_context *ctx, double **ne3d, double **kappa3d)
+{
+    if (!ctx) return fail(CBET_EINVAL, "NULL context");
+    if (ne3d) *ne3d = ctx->ne3d;
+    if (kappa3d) *kappa3d = ctx->kap3d;
+    return CBET_OK;
+}
+
+// The launch must describe the grid / ray geometry the workspace was sized for.
+static int check_geometry(const cbet_context *ctx, const cbet_params *p)
+{
+    const cbet_params &q = ctx->p;
+    if (p->nx != q.nx || p->ny != q.ny || p->nz != q.nz || p->xmin != q.xmin || p->xmax != q.xmax ||
+        p->ymin != q.ymin || p->ymax != q.ymax || p->zmin != q.zmin || p->zmax != q.zmax ||
+        p->rays_per_zone != q.rays_per_zone || p->nbeams != q.nbeams || p->nprofile != q.nprofile ||
+        p->max_threads != q.max_threads || p->threads_per_block != q.threads_per_block ||
+        p->courant_mult != q.courant_mult)
+        return fail(CBET_EINVAL, "launch parameters do not match the geometry the context was created for");
+    return CBET_OK;
+}
+
+int cbet_tabulate_plasma(cbet_context *ctx, const cbet_params *p, const double *te_data_g,
+                         const double *r_data_g, const double *ne_data_g, void *stream)
+{
+    if (!ctx) return fail(CBET_EINVAL, "NULL context");
+    if (int rc = validate(p)) return rc;
+    if (int rc = check_geometry(ctx, p)) return rc;
+    if (!te_data_g || !r_data_g || !ne_data_g) return fail(CBET_EINVAL, "NULL profile pointer");
+    DeviceGuard guard;
+    CBET_HIP(hipSetDevice(ctx->gpu));
+    TabulateArgs t{};
+    t.nx = p->nx; t.ny = p->ny; t.nz = p->nz; t.nprofile = p->nprofile;
+    t.xmin = p->xmin; t.ymin = p->ymin; t.zmin = p->zmin;
+    t.dx = ctx->d.dx; t.dy = ctx->d.dy; t.dz = ctx->d.dz; t.dt = ctx->d.dt;
+    t.ncrit = ctx->d.ncrit;
+    t.r = r_data_g; t.ne = ne_data_g; t.te = te_data_g;
+    t.ne3d = ctx->ne3d; t.kap3d = ctx->kap3d;
+    CBET_HIP(launch_tabulate(t, (hipStream_t)stream));
+    return CBET_OK;
+}
+
+int cbet_trace_nodes(int b, unsigned nindices, const double *ne3d, const double *kappa3d,
+                     double *edep, const double *bbeam_norm, const double *beam_norm,
+                     const double *pow_r, const double *phase_r, double xconst, double yconst,
+                     double zconst, const cbet_params *p, cbet_context *ctx, void *stream)
+{
+    if (!ctx) return fail(CBET_EINVAL, "NULL context");
+    if (int rc = validate(p)) return rc;
+    if (int rc = check_geometry(ctx, p)) return rc;
+    if (!edep || !beam_norm || !pow_r || !phase_r) return fail(CBET_EINVAL, "NULL device pointer");
+    if (nindices == 0) return CBET_OK;  // launch_ray_XZ.cu:155: the ray loop does not run
+    if ((int)nindices != ctx->d.nindices)
+        return fail(CBET_EINVAL, "nindices=%u but def.cuh:129 gives %d for these parameters", nindices, ctx->d.nindices);
+
+    int beam_lo = p->beam_lo, beam_hi = p->beam_hi;
+    if (beam_hi <= beam_lo) {  // launch_ray_XZ.cu:123 with grid.x = nbeams/nGPUs (main.cu:161)
+        const int ng = p->ngpus > 0 ? p->ngpus : 1;
+        const int per = p->nbeams / ng;
+        beam_lo = b * per;
+        beam_hi = beam_lo + per;
+    }
+    if (beam_lo < 0 || beam_hi > p->nbeams || beam_hi < beam_lo)
+        return fail(CBET_EINVAL, "beam range [%d,%d) outside [0,%d)", beam_lo, beam_hi, p->nbeams);
+    if (beam_hi == beam_lo || ctx->nlive == 0) return CBET_OK;
+
+    int variant = p->kernel_variant;
+    if (variant == CBET_KERNEL_DEFAULT) variant = CBET_KERNEL_LDS_COMBINE;
+    if (variant != CBET_KERNEL_GLOBAL_ATOMICS && variant != CBET_KERNEL_LDS_COMBINE)
+        return fail(CBET_EINVAL, "unknown kernel_variant %d", p->kernel_variant);
+    int wl = p->lds_window_log2 ? p->lds_window_log2 : 3;
+    if (wl != 3 && wl != 4) return fail(CBET_EINVAL, "lds_window_log2 must be 3 or 4");
+
+    const cbet_derived &d = ctx->d;
+    TraceArgs a{};
+    a.nx = p->nx; a.ny = p->ny; a.nz = p->nz;
+    a.xmin = p->xmin; a.ymin = p->ymin; a.zmin = p->zmin;
+    a.dx = d.dx; a.dy = d.dy; a.dz = d.dz; a.dt = d.dt;
+    a.inv_dx = 1 / d.dx; a.inv_dy = 1 / d.dy; a.inv_dz = 1 / d.dz;      // launch_ray_XZ.cu:276-278
+    a.xlo = p->xmin - (d.dx / 2.0); a.xhi = p->xmax + (d.dx / 2.0);      // :352
+    a.ylo = p->ymin - (d.dy / 2.0); a.yhi = p->ymax + (d.dy / 2.0);      // :353
+    a.zlo = p->zmin - (d.dz / 2.0); a.zhi = p->zmax + (d.dz / 2.0);      // :354
+    a.tol_x = 0.5001 * d.dx; a.tol_y = 0.5001 * d.dy; a.tol_z = 0.5001 * d.dz;  // :164-176
+    a.xconst = xconst; a.yconst = yconst; a.zconst = zconst;
+    a.nt = d.nt; a.absorption = p->absorption;
+    a.rpz = p->rays_per_zone; a.zones = d.zones_spanned; a.nrays_x = d.nrays_x;
+    a.z_launch = kFocal - d.dz / 2;                                       // :97
+    a.uray_mult = d.uray_mult; a.omega = d.omega; a.ncrit = d.ncrit;
+    a.xlaunch = ctx->xlaunch; a.ylaunch = ctx->ylaunch;
+    a.live = ctx->live; a.nlive = ctx->nlive;
+    a.beam_lo = beam_lo; a.nbeams_local = beam_hi - beam_lo;
+    a.bundles_per_beam = (ctx->nlive + kWave - 1) / kWave;
+    a.total_bundles = (long)a.nbeams_local * a.bundles_per_beam;
+    a.shard_index = p->shard_count > 1 ? p->shard_index : 0;
+    a.shard_count = p->shard_count > 1 ? p->shard_count : 1;
+    a.ne3d = ne3d ? ne3d : ctx->ne3d;
+    a.kap3d = kappa3d ? kappa3d : ctx->kap3d;
+    a.beam_norm = beam_norm; a.bbeam_norm = bbeam_norm; a.pow_r = pow_r; a.phase_r = phase_r;
+    a.edep = edep;
+    a.counters = ctx->counters;
+
+    DeviceGuard guard;
+    CBET_HIP(hipSetDevice(ctx->gpu));
+    CBET_HIP(launch_trace(a, variant, wl, (hipStream_t)stream));
+    return CBET_OK;
+}
+
+// One lazily created workspace per device for callers that pass ctx == NULL (the reference's
+// launch site has nothing to pass).  Recreated when the geometry changes.
+static std::mutex g_ctx_mu;
+static std::map<int, cbet_context *> g_default_ctx;
+
+static int default_context(const cbet_params *p, cbet_context **out)
+{
+    int dev = 0;
+    CBET_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    auto it = g_default_ctx.find(dev);
+    if (it != g_default_ctx.end()) {
+        if (check_geometry(it->second, p) == CBET_OK) {
+            *out = it->second;
+            return CBET_OK;
+        }
+        cbet_context_destroy(it->second);
+        g_default_ctx.erase(it);
+    }
+    cbet_context *ctx = nullptr;
+    if (int rc = cbet_context_create(&ctx, p, dev)) return rc;
+    g_default_ctx[dev] = ctx;
+    *out = ctx;
+    return CBET_OK;
+}
+
+int cbet_launch_ray_XYZ(int b, unsigned nindices, double *te_data_g, double *r_data_g,
+                        double *ne_data_g, double *edep, double *bbeam_norm, double *beam_norm,
+                        double *pow_r, double *phase_r, double xconst, double yconst,
+                        double zconst, const cbet_params *p, cbet_context *ctx, void *stream)
+{
+    if (int rc = validate(p)) return rc;
+    if (!ctx) {
+        if (int rc = default_context(p, &ctx)) return rc;
+    }
+    if (int rc = cbet_tabulate_plasma(ctx, p, te_data_g, r_data_g, ne_data_g, stream)) return rc;
+    return cbet_trace_nodes(b, nindices, nullptr, nullptr, edep, bbeam_norm, beam_norm, pow_r, phase_r,
+                            xconst, yconst, zconst, p, ctx, stream);
+}
+
+}  // extern "C"

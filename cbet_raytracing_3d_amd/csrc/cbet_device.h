@@ -1,0 +1,73 @@
+// cbet_device.h -- argument blocks shared by the host ABI (cbet_abi.cpp) and the gfx950 kernels
+// (cbet_kernels.hip).  Internal; the public boundary is include/cbet_mi355x.h.
+#ifndef CBET_DEVICE_H_
+#define CBET_DEVICE_H_
+
+#include <hip/hip_runtime_api.h>
+
+#include "cbet_mi355x.h"
+
+namespace cbet {
+
+// Physical constants, /root/reference/def.cuh:61-69, 78, 91, 119, 55-56.
+constexpr double kC = 29979245800.0;
+constexpr double kE0 = 8.85418782e-12;
+constexpr double kMe = 9.10938356e-31;
+constexpr double kEc = 1.60217662e-19;
+constexpr double kLambda = 1.053e-4 / 3.0;
+constexpr double kSigma = 0.0375;
+constexpr double kIntensity = 1.0e14;
+constexpr double kFocal = 0.1;
+constexpr double kBeamMin = -450.0e-4;
+constexpr double kBeamMax = 450.0e-4;
+
+constexpr unsigned kEmptyTag = 0xFFFFFFFFu;
+constexpr int kWave = 64;
+
+// Device counter slots (unsigned long long each); mirrors cbet_counters.
+enum CounterSlot { kCntSteps = 0, kCntRays = 1, kCntGlobalAtomics = 2, kCntEvictions = 3, kCntSlots = 8 };
+
+// Everything the tabulation kernel needs.
+struct TabulateArgs {
+    int nx, ny, nz, nprofile;
+    double xmin, ymin, zmin;
+    double dx, dy, dz, dt;
+    double ncrit;
+    const double *r, *ne, *te;  // device, nprofile each
+    double *ne3d, *kap3d;       // device, nx*ny*nz each
+};
+
+// Everything the trace kernel needs, passed by value as the kernel argument.
+struct TraceArgs {
+    // grid (def.cuh:35-53)
+    int nx, ny, nz;
+    double xmin, ymin, zmin;
+    double dx, dy, dz, dt;
+    double inv_dx, inv_dy, inv_dz;          // (1/dx) of launch_ray_XZ.cu:276-278
+    double xlo, xhi, ylo, yhi, zlo, zhi;    // xmin-(dx/2.0) ... of launch_ray_XZ.cu:352-354
+    double tol_x, tol_y, tol_z;             // 0.5001*dx of launch_ray_XZ.cu:164-176
+    double xconst, yconst, zconst;          // main.cu:156-159
+    int nt, absorption;
+    // launch geometry (launch_ray_XZ.cu:65-115)
+    int rpz, zones, nrays_x;
+    double z_launch;                        // focal_length - dz/2
+    double uray_mult, omega, ncrit;
+    const double *xlaunch, *ylaunch;        // running-sum launch coordinates, dx/2 already added
+    const int *live;                        // compacted thread-ray ids (beam independent)
+    int nlive;
+    // work split
+    int beam_lo, nbeams_local, bundles_per_beam;
+    long total_bundles;
+    int shard_index, shard_count;
+    // tables
+    const double *ne3d, *kap3d;
+    const double *beam_norm, *bbeam_norm, *pow_r, *phase_r;
+    double *edep;
+    unsigned long long *counters;
+};
+
+hipError_t launch_tabulate(const TabulateArgs &a, hipStream_t stream);
+hipError_t launch_trace(const TraceArgs &a, int variant, int window_log2, hipStream_t stream);
+
+}  // namespace cbet
+#endif

@@ -1,0 +1,212 @@
+// cbet_host.cpp -- cbet_ray_tracing(): the MI355X counterpart of rayTracing()
+// (/root/reference/main.cu:96-232).  Same phases -- host tables, per-device upload, one launch
+// per device from its own host thread, combine, timers -- with two differences that are the point
+// of the redesign:
+//   * rays are split across devices as interleaved ray bundles (every device sees every beam),
+//     not as contiguous blocks of nbeams/nGPUs beams (launch_ray_XZ.cu:123), so 60 beams on 8
+//     devices lose nothing to integer division and the load is even;
+//   * the per-device grids are summed on the devices by one RCCL all-reduce over xGMI, replacing
+//     the D2H copies and the host += loop (main.cu:178-210).  Device 0's copy of the sum is then
+//     ADDED into the caller's host grid, keeping rayTracing()'s "edep +=" contract.
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "cbet_mi355x.h"
+
+namespace cbet {
+int fail(int code, const char *fmt, ...);
+}
+
+namespace {
+
+double now_s()
+{
+    using clk = std::chrono::steady_clock;
+    return std::chrono::duration<double>(clk::now().time_since_epoch()).count();
+}
+
+struct DeviceJob {
+    int gpu = 0;
+    int rc = CBET_OK;
+    std::string err;
+    cbet_context *ctx = nullptr;
+    double *d_beam_norm = nullptr, *d_bbeam_norm = nullptr, *d_pow_r = nullptr, *d_phase_r = nullptr;
+    double *d_ne = nullptr, *d_te = nullptr, *d_r = nullptr, *d_edep = nullptr;
+    hipStream_t stream = nullptr;
+    cbet_counters counters{};
+};
+
+void note(DeviceJob &j, int rc)
+{
+    if (rc != CBET_OK && j.rc == CBET_OK) {
+        j.rc = rc;
+        j.err = cbet_last_error();
+    }
+}
+
+void release(DeviceJob &j)
+{
+    (void)hipSetDevice(j.gpu);
+    if (j.stream) (void)hipStreamDestroy(j.stream);
+    cbet_context_destroy(j.ctx);
+    for (double *p : {j.d_beam_norm, j.d_bbeam_norm, j.d_pow_r, j.d_phase_r, j.d_ne, j.d_te, j.d_r, j.d_edep})
+        if (p) (void)hipFree(p);
+}
+
+}  // namespace
+
+extern "C" int cbet_ray_tracing(const double *te_profile, const double *r_profile,
+                                const double *ne_profile, double *edep, const cbet_params *p,
+                                const double *beam_norm, const int *gpus, int ngpu, double *timers,
+                                cbet_counters *counters)
+{
+    if (!te_profile || !r_profile || !ne_profile || !edep || !p)
+        return cbet::fail(CBET_EINVAL, "cbet_ray_tracing: NULL argument");
+    if (ngpu < 1) return cbet::fail(CBET_EINVAL, "cbet_ray_tracing: ngpu < 1");
+    cbet_derived d;
+    if (int rc = cbet_derive(p, &d)) return rc;
+    if (!beam_norm) {
+        if (p->nbeams > 60) return cbet::fail(CBET_EINVAL, "nbeams > 60 needs an explicit beam_norm table");
+        beam_norm = cbet_omega60_beam_norm();
+    }
+    const double t1 = now_s();
+
+    // main.cu:102-110, 121-129: host tables
+    std::vector<double> phase_r(CBET_NPHASE), pow_r(CBET_NPHASE), bbeam(4 * (size_t)p->nbeams);
+    cbet_host_power_table(phase_r.data(), pow_r.data());
+    cbet_host_beam_trig(beam_norm, p->nbeams, bbeam.data());
+
+    const size_t edep_bytes = sizeof(double) * (size_t)d.edep_size;
+    const size_t nr = (size_t)p->nprofile;
+    std::vector<DeviceJob> jobs(ngpu);
+    for (int i = 0; i < ngpu; ++i) jobs[i].gpu = gpus ? gpus[i] : i;
+
+    // main.cu:133-152: allocate + upload per device (plus the workspace, and a zeroed grid: the
+    // reference accumulates into memory it never clears)
+    auto setup = [&](DeviceJob &j) {
+        const int g = j.gpu;
+        note(j, cbet_safeGPUAlloc((void **)&j.d_beam_norm, sizeof(double) * 3 * p->nbeams, g));
+        note(j, cbet_safeGPUAlloc((void **)&j.d_bbeam_norm, sizeof(double) * 4 * p->nbeams, g));
+        note(j, cbet_safeGPUAlloc((void **)&j.d_pow_r, sizeof(double) * CBET_NPHASE, g));
+        note(j, cbet_safeGPUAlloc((void **)&j.d_phase_r, sizeof(double) * CBET_NPHASE, g));
+        note(j, cbet_safeGPUAlloc((void **)&j.d_ne, sizeof(double) * nr, g));
+        note(j, cbet_safeGPUAlloc((void **)&j.d_te, sizeof(double) * nr, g));
+        note(j, cbet_safeGPUAlloc((void **)&j.d_r, sizeof(double) * nr, g));
+        note(j, cbet_safeGPUAlloc((void **)&j.d_edep, edep_bytes, g));
+        if (j.rc) return;
+        note(j, cbet_moveToAndFromGPU(j.d_beam_norm, (void *)beam_norm, sizeof(double) * 3 * p->nbeams, g));
+        note(j, cbet_moveToAndFromGPU(j.d_bbeam_norm, bbeam.data(), sizeof(double) * 4 * p->nbeams, g));
+        note(j, cbet_moveToAndFromGPU(j.d_pow_r, pow_r.data(), sizeof(double) * CBET_NPHASE, g));
+        note(j, cbet_moveToAndFromGPU(j.d_phase_r, phase_r.data(), sizeof(double) * CBET_NPHASE, g));
+        note(j, cbet_moveToAndFromGPU(j.d_ne, (void *)ne_profile, sizeof(double) * nr, g));
+        note(j, cbet_moveToAndFromGPU(j.d_te, (void *)te_profile, sizeof(double) * nr, g));
+        note(j, cbet_moveToAndFromGPU(j.d_r, (void *)r_profile, sizeof(double) * nr, g));
+        if (j.rc) return;
+        note(j, cbet_context_create(&j.ctx, p, g));
+        if (j.rc) return;
+        if (hipSetDevice(g) != hipSuccess || hipStreamCreate(&j.stream) != hipSuccess ||
+            hipMemsetAsync(j.d_edep, 0, edep_bytes, j.stream) != hipSuccess ||
+            hipStreamSynchronize(j.stream) != hipSuccess) {
+            j.rc = CBET_EHIP;
+            j.err = "stream/memset setup failed";
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (auto &j : jobs) th.emplace_back(setup, std::ref(j));
+        for (auto &t : th) t.join();
+    }
+    auto first_error = [&]() -> int {
+        for (auto &j : jobs)
+            if (j.rc) return cbet::fail(j.rc, "device %d: %s", j.gpu, j.err.c_str());
+        return CBET_OK;
+    };
+    if (int rc = first_error()) {
+        for (auto &j : jobs) release(j);
+        return rc;
+    }
+    const double t2 = now_s();
+
+    // main.cu:166-176: one host thread per device launches and waits
+    auto run = [&](DeviceJob &j, int index) {
+        cbet_params q = *p;
+        q.beam_lo = 0;
+        q.beam_hi = p->nbeams;
+        q.shard_index = index;
+        q.shard_count = ngpu;
+        (void)hipSetDevice(j.gpu);
+        note(j, cbet_launch_ray_XYZ(index, (unsigned)d.nindices, j.d_te, j.d_r, j.d_ne, j.d_edep,
+                                    j.d_bbeam_norm, j.d_beam_norm, j.d_pow_r, j.d_phase_r, d.xconst,
+                                    d.yconst, d.zconst, &q, j.ctx, j.stream));
+        if (j.rc) return;
+        note(j, cbet_context_counters(j.ctx, j.stream, &j.counters, 0));  // synchronises the stream
+    };
+    {
+        std::vector<std::thread> th;
+        for (int i = 0; i < ngpu; ++i) th.emplace_back(run, std::ref(jobs[i]), i);
+        for (auto &t : th) t.join();
+    }
+    if (int rc = first_error()) {
+        for (auto &j : jobs) release(j);
+        return rc;
+    }
+    const double t3 = now_s();
+
+    // Combine: RCCL all-reduce over xGMI (replaces main.cu:178-210), then "edep +=" on the host.
+    int rc = CBET_OK;
+    if (ngpu > 1) {
+        std::vector<ncclComm_t> comms(ngpu);
+        std::vector<int> devs(ngpu);
+        for (int i = 0; i < ngpu; ++i) devs[i] = jobs[i].gpu;
+        ncclResult_t nr_ = ncclCommInitAll(comms.data(), ngpu, devs.data());
+        if (nr_ != ncclSuccess) {
+            rc = cbet::fail(CBET_ECOMM, "ncclCommInitAll: %s", ncclGetErrorString(nr_));
+        } else {
+            ncclGroupStart();
+            for (int i = 0; i < ngpu && nr_ == ncclSuccess; ++i) {
+                (void)hipSetDevice(jobs[i].gpu);
+                nr_ = ncclAllReduce(jobs[i].d_edep, jobs[i].d_edep, (size_t)d.edep_size, ncclDouble, ncclSum,
+                                    comms[i], jobs[i].stream);
+            }
+            ncclResult_t ge = ncclGroupEnd();
+            if (nr_ == ncclSuccess) nr_ = ge;
+            for (int i = 0; i < ngpu; ++i) {
+                (void)hipSetDevice(jobs[i].gpu);
+                (void)hipStreamSynchronize(jobs[i].stream);
+            }
+            if (nr_ != ncclSuccess) rc = cbet::fail(CBET_ECOMM, "ncclAllReduce: %s", ncclGetErrorString(nr_));
+            for (auto &c : comms) ncclCommDestroy(c);
+        }
+    }
+    if (rc == CBET_OK) {
+        std::vector<double> staging((size_t)d.edep_size);
+        rc = cbet_moveToAndFromGPU(staging.data(), jobs[0].d_edep, edep_bytes, jobs[0].gpu);
+        if (rc == CBET_OK)
+            for (long i = 0; i < d.edep_size; ++i) edep[i] += staging[i];  // main.cu:206
+    }
+    if (counters) {
+        std::memset(counters, 0, sizeof *counters);
+        for (auto &j : jobs) {
+            counters->ray_steps += j.counters.ray_steps;
+            counters->rays_traced += j.counters.rays_traced;
+            counters->global_atomics += j.counters.global_atomics;
+            counters->lds_evictions += j.counters.lds_evictions;
+        }
+    }
+    for (auto &j : jobs) release(j);
+    const double t4 = now_s();
+    if (timers) {  // main.cu:219-231: Init, Tracing, Combining, Total
+        timers[0] = t2 - t1;
+        timers[1] = t3 - t2;
+        timers[2] = t4 - t3;
+        timers[3] = t4 - t1;
+    }
+    return rc;
+}

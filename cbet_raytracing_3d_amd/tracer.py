@@ -1,0 +1,116 @@
+"""RayTracer: torch-held device buffers around the C-ABI launch, and the multi-GPU step.
+
+torch is plumbing here -- device memory, streams and torch.distributed (backend "nccl" = RCCL over
+xGMI).  All computation happens in libcbet_mi355x.so through cbet_raytracing_3d_amd.api.
+
+The multi-GPU scheme replaces main.cu:166-210 (/root/reference): instead of contiguous blocks of
+nbeams/nGPUs beams per device and a host-side sum, every rank traces an interleaved 1/world_size
+share of the ray bundles of EVERY beam into its private (nx+2)(ny+2)(nz+2) grid and the grids are
+summed with one all-reduce.
+"""
+import numpy as np
+import torch
+
+from . import api
+
+
+class RayTracer:
+    """One device's share of a ray-tracing pass.
+
+    Mirrors the device-side state rayTracing() sets up per GPU (main.cu:133-152): the seven small
+    read-only arrays uploaded once, a deposition grid, and the launch constants of main.cu:156-159.
+    """
+
+    def __init__(self, params, r_profile, ne_profile, te_profile, beam_norm=None, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("RayTracer needs a HIP device (no CPU fallback)")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None \
+            else torch.device(device)
+        self.gpu = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.params = params.copy()
+        self.derived = api.derive(self.params)
+        if beam_norm is None:
+            beam_norm = api.omega60_beam_norm()[: self.params.nbeams]
+        beam_norm = np.ascontiguousarray(beam_norm, dtype=np.float64).reshape(-1, 3)
+        if beam_norm.shape[0] != self.params.nbeams:
+            raise ValueError("beam_norm has %d rows, params.nbeams=%d" % (beam_norm.shape[0], self.params.nbeams))
+        phase_r, pow_r = api.host_power_table()
+        bbeam = api.host_beam_trig(beam_norm)
+
+        def up(a):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
+
+        self.d_beam_norm, self.d_bbeam_norm = up(beam_norm), up(bbeam)
+        self.d_pow_r, self.d_phase_r = up(pow_r), up(phase_r)
+        self.d_r, self.d_ne, self.d_te = up(r_profile), up(ne_profile), up(te_profile)
+        for t in (self.d_r, self.d_ne, self.d_te):
+            if t.numel() != self.params.nprofile:
+                raise ValueError("profile length != params.nprofile")
+        self.ctx = api.Context(self.params, self.gpu)
+        self.grid_shape = (self.params.nx + 2, self.params.ny + 2, self.params.nz + 2)
+
+    def new_grid(self):
+        return torch.zeros(self.grid_shape, dtype=torch.float64, device=self.device)
+
+    def launch(self, edep, shard_index=0, shard_count=1, beam_lo=0, beam_hi=None,
+               kernel_variant=None, lds_window_log2=None, use_host_trig=True):
+        """Enqueue one launch_ray_XYZ on torch's current stream, accumulating into `edep`."""
+        if edep.dtype != torch.float64 or not edep.is_contiguous() or tuple(edep.shape) != self.grid_shape:
+            raise ValueError("edep must be a contiguous float64 tensor of shape %s" % (self.grid_shape,))
+        p = self.params.copy(beam_lo=beam_lo,
+                             beam_hi=self.params.nbeams if beam_hi is None else beam_hi,
+                             shard_index=shard_index, shard_count=shard_count)
+        if kernel_variant is not None:
+            p.kernel_variant = kernel_variant
+        if lds_window_log2 is not None:
+            p.lds_window_log2 = lds_window_log2
+        d = self.derived
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        api.launch_ray_XYZ(0, d.nindices, self.d_te, self.d_r, self.d_ne, edep,
+                           self.d_bbeam_norm if use_host_trig else None, self.d_beam_norm,
+                           self.d_pow_r, self.d_phase_r, d.xconst, d.yconst, d.zconst, p,
+                           ctx=self.ctx, stream=stream)
+        return edep
+
+    def counters(self, reset=False):
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        return self.ctx.counters(stream, reset)
+
+    def node_tables(self):
+        """Copies of the context's node tables (ne3d, kappa3d) as numpy arrays, for tests."""
+        n = self.params.nx * self.params.ny * self.params.nz
+        a, b = self.ctx.tables()
+        out = []
+        for addr in (a, b):
+            h = np.empty(n)
+            api.moveToAndFromGPU(h, addr, 8 * n, self.gpu)
+            out.append(h.reshape(self.params.nx, self.params.ny, self.params.nz))
+        return out
+
+    def close(self):
+        self.ctx.close()
+
+
+def shard_of_rank(rank, world_size):
+    """(shard_index, shard_count) of a rank: bundle g belongs to rank g % world_size."""
+    if not 0 <= rank < world_size:
+        raise ValueError("rank outside [0, world_size)")
+    return rank, world_size
+
+
+def allreduce_grid(edep, group=None):
+    """Sum the per-rank deposition grids in place (RCCL all-reduce over xGMI with backend
+    "nccl"; gloo on CPU tensors in the tests).  Replaces main.cu:178-210.  No-op without an
+    initialised process group."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(edep, op=dist.ReduceOp.SUM, group=group)
+    return edep
+
+
+def traced_pass(tracer, edep, rank=0, world_size=1, group=None, **launch_kw):
+    """One full pass over the beams on `world_size` ranks: zero, trace this rank's share, combine."""
+    edep.zero_()
+    si, sc = shard_of_rank(rank, world_size)
+    tracer.launch(edep, shard_index=si, shard_count=sc, **launch_kw)
+    return allreduce_grid(edep, group)

@@ -1,0 +1,209 @@
+/*
+ * cbet_mi355x.h -- C ABI of the MI355X-native ray-integrator path.
+ *
+ * This is the drop-in boundary for the ONE hot path of abowman6/CBET_RayTracing_3D: the
+ * launch_ray_XYZ kernel launch (launch_ray_XZ.cu:117-121, launched at main.cu:166-176), the two
+ * multi_gpu helpers around it (multi_gpu.cuh:6-7) and the rayTracing() orchestrator that strings
+ * them together (main.cu:96-232).  Plain pointers and sizes only; no C++ or torch types.
+ * Citations are into /root/reference/.
+ *
+ * Conventions
+ *   - every function that can fail returns an int status: CBET_OK (0) or a negative CBET_E* code;
+ *     cbet_last_error() returns a thread-local message.  (The reference returns bool + prints to
+ *     cout and its call sites ignore the result, main.cu:136-151; here nothing is fire-and-forget.)
+ *   - "device pointer" = memory of the HIP device the call names; streams are hipStream_t passed
+ *     as void* (NULL = the device's default stream).
+ *   - all arithmetic is fp64; grids are dense C-order arrays.
+ */
+#ifndef CBET_MI355X_H_
+#define CBET_MI355X_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CBET_OK 0
+#define CBET_EINVAL (-1)   /* bad argument / unsupported parameter combination */
+#define CBET_EHIP (-2)     /* a HIP runtime call failed (message has hipGetErrorString) */
+#define CBET_ENOMEM (-3)   /* device out of memory (safeGPUAlloc's free<size guard) */
+#define CBET_ENODEVICE (-4)/* GPUIndex == -1 / no such device (moveToAndFromGPU's guard) */
+#define CBET_ECOMM (-5)    /* RCCL failure in the multi-GPU orchestrator */
+
+#define CBET_NPHASE 2001   /* length of pow_r / phase_r, main.cu:102-103 */
+
+/* Kernel formulations selectable at run time (cbet_params.kernel_variant). */
+#define CBET_KERNEL_DEFAULT 0        /* the library's best parity-exact kernel */
+#define CBET_KERNEL_GLOBAL_ATOMICS 1 /* one ray per lane, 8 global fp64 atomics per step */
+#define CBET_KERNEL_LDS_COMBINE 2    /* wave-private LDS write-combining of the deposits */
+
+/*
+ * Run-time counterpart of def.cuh's compile-time configuration (def.cuh:33-131).  Fill with
+ * cbet_params_default() and override fields; every launch validates it.
+ */
+typedef struct cbet_params {
+    int nx, ny, nz;              /* def.cuh:35-46 xyz_size (nodes per axis, >= 3)              */
+    double xmin, xmax;           /* def.cuh:37-38                                              */
+    double ymin, ymax;           /* def.cuh:42-43                                              */
+    double zmin, zmax;           /* def.cuh:47-48                                              */
+    int nbeams;                  /* def.cuh:58  rows in beam_norm                              */
+    int rays_per_zone;           /* def.cuh:71                                                 */
+    double courant_mult;         /* def.cuh:80                                                 */
+    int absorption;              /* def.cuh:118 (1: absorb; else bookkeeping mode)             */
+    int nprofile;                /* def.cuh:33  nr, rows of the radial ne/Te profile           */
+    int max_threads;             /* def.cuh:125 (enters the reference's traced-id rule)        */
+    int threads_per_block;       /* def.cuh:127 (enters the reference's traced-id rule)        */
+    int ngpus;                   /* def.cuh:116 nGPUs: with beam_hi<=beam_lo, launch `b` owns  */
+                                 /* beams [b*(nbeams/ngpus), (b+1)*(nbeams/ngpus)), as at      */
+                                 /* launch_ray_XZ.cu:123                                       */
+    int beam_lo, beam_hi;        /* explicit beam range [lo,hi) overriding the ngpus rule      */
+    int shard_index, shard_count;/* ray-bundle interleaved sharding inside the beam range:     */
+                                 /* bundle g is traced iff g % shard_count == shard_index      */
+                                 /* (shard_count<=1: everything)                               */
+    int kernel_variant;          /* CBET_KERNEL_*                                              */
+    int lds_window_log2;         /* LDS_COMBINE: log2 of the cubic window edge (3 or 4; 0=auto)*/
+    int reserved[6];
+} cbet_params;
+
+/* Quantities the reference derives in def.cuh / main.cu:156-161, evaluated in the same order. */
+typedef struct cbet_derived {
+    double dx, dy, dz, dt;       /* def.cuh:39,44,49,81                                        */
+    int nt;                      /* def.cuh:83-84                                              */
+    int zones_spanned;           /* launch_ray_XZ.cu:69                                        */
+    int nrays_x, nrays_y, nrays; /* def.cuh:75-77                                              */
+    double omega, ncrit;         /* def.cuh:68-69                                              */
+    double uray_mult;            /* def.cuh:92                                                 */
+    double xconst, yconst, zconst; /* main.cu:156-159 dedx_const, dedy_const, dedz_const       */
+    long threads_per_beam;       /* def.cuh:128                                                */
+    int nindices;                /* def.cuh:129                                                */
+    int grid_y;                  /* main.cu:161                                                */
+    long edep_size;              /* def.cuh:131 (nx+2)(ny+2)(nz+2)                             */
+    long ntraced_ids;            /* thread-ray ids per beam the launch shape visits            */
+    long nlive_rays;             /* of those, rays inside the beam radius (per beam)           */
+} cbet_derived;
+
+/* Counters a launch accumulates on the device (read back with cbet_context_counters). */
+typedef struct cbet_counters {
+    unsigned long long ray_steps;        /* integrator iterations that reached the deposition  */
+    unsigned long long rays_traced;      /* live rays launched                                 */
+    unsigned long long global_atomics;   /* fp64 atomics that went to HBM                      */
+    unsigned long long lds_evictions;    /* LDS_COMBINE: slots written back before the end     */
+    unsigned long long reserved[4];
+} cbet_counters;
+
+typedef struct cbet_context cbet_context; /* per-device workspace: node tables, ray list, counters */
+
+/* ---- configuration ------------------------------------------------------------------------ */
+const char *cbet_last_error(void);
+const char *cbet_version(void);
+
+/* def.cuh defaults at grid size n (n = 100 is the shipped configuration). */
+int cbet_params_default(cbet_params *p, int n);
+int cbet_derive(const cbet_params *p, cbet_derived *d);
+
+/*
+ * The beam-independent launch list, in the order the trace kernel consumes it.  The beam cross
+ * section is cut into 8x8-ray patches (Morton order); 64 consecutive entries = one patch = one ray
+ * bundle = one wavefront.  An entry is the thread-ray id (launch_ray_XZ.cu:125,156) of that ray,
+ * or -1 for a hole: a ray the reference launch shape never visits or one that fails init()'s
+ * beam-radius test (:94,114).  Bundle g = beam_local * (n/64) + entry/64 is traced by shard
+ * g % shard_count.  Writes min(n, cap) entries to out (may be NULL) and n to *count.
+ */
+int cbet_live_ray_list(const cbet_params *p, int *out, long cap, long *count);
+
+/* omega_beams.h:1-62 : the 60 OMEGA port normals, double[60][3], row-major. */
+const double *cbet_omega60_beam_norm(void);
+/* main.cu:24-32 + 102-110 : phase_r = span(0,0.1,2001), pow_r = exp(-((r/sigma)^2)^2.5); host arrays. */
+int cbet_host_power_table(double *phase_r, double *pow_r);
+/* main.cu:121-129 : better_beam_norm, 4 doubles per beam {cos t1, sin t1, cos t2, sin t2}; host arrays. */
+int cbet_host_beam_trig(const double *beam_norm, int nbeams, double *bbeam_norm);
+/* main.cu:249-260 : read exactly nprofile rows "r value" of a profile file into r[] and v[]. */
+int cbet_read_profile(const char *path, int nprofile, double *r, double *v);
+
+/* ---- multi_gpu.cuh:6-7 helpers -------------------------------------------------------------- */
+/*
+ * safeGPUAlloc (multi_gpu.cpp:3-28): makes `gpu` current (and leaves it current), fails with
+ * CBET_ENOMEM when free < size, otherwise hipMalloc.  Returns CBET_OK where the reference
+ * returns true.
+ */
+int cbet_safeGPUAlloc(void **dst, size_t size, int gpu);
+/*
+ * moveToAndFromGPU (multi_gpu.cpp:44-59): gpu == -1 -> CBET_ENODEVICE; blocking copy with the
+ * direction inferred from the pointers (hipMemcpyDefault); the caller's current device is
+ * preserved.
+ */
+int cbet_moveToAndFromGPU(void *dst, void *src, size_t size, int gpu);
+/* cudaFree counterpart for memory from cbet_safeGPUAlloc (main.cu:180-187). */
+int cbet_gpuFree(void *ptr, int gpu);
+
+/* ---- workspace ------------------------------------------------------------------------------ */
+/*
+ * Allocates the per-device workspace a launch needs (node tables ne3d/kappa3d of nx*ny*nz doubles
+ * each, the compacted live-ray list, counters) so that cbet_launch_ray_XYZ itself never
+ * allocates or synchronises (graph-capturable).  The context is bound to `gpu` and to the grid /
+ * ray geometry in *p; sharding, beam range and kernel variant may change per launch.
+ */
+int cbet_context_create(cbet_context **ctx, const cbet_params *p, int gpu);
+int cbet_context_destroy(cbet_context *ctx);
+/* Synchronises `stream`, copies the counters to *out and, if reset != 0, zeroes them. */
+int cbet_context_counters(cbet_context *ctx, void *stream, cbet_counters *out, int reset);
+/* Device pointers of the node tables (for tests / the 3-D plasma entry below). */
+int cbet_context_tables(cbet_context *ctx, double **ne3d, double **kappa3d);
+
+/* ---- the hot path ---------------------------------------------------------------------------- */
+/*
+ * launch_ray_XYZ (launch_ray_XZ.cu:117-121; launch site main.cu:171-174).  Same thirteen
+ * arguments, same order and meaning:
+ *   b          GPU ordinal of the reference's beam split (see cbet_params.ngpus / beam_lo)
+ *   nindices   strided passes per thread (def.cuh:129) -- enters the traced-id rule only
+ *   te_data_g, r_data_g, ne_data_g   device, nprofile doubles each (main.cu:149-151)
+ *   edep       device, (nx+2)(ny+2)(nz+2) doubles, x-major/z-fastest with a one-cell halo
+ *              (launch_ray_XZ.cu:5-7); ACCUMULATED into, never cleared (caller zeroes it)
+ *   bbeam_norm device, 4*nbeams doubles from cbet_host_beam_trig; the reference uploads but
+ *              ignores it (main.cu:146) -- here it supplies the rotation cos/sin so that launch
+ *              points equal the host libm's to the last bit.  NULL: trig evaluated on the device.
+ *   beam_norm  device, 3*nbeams doubles
+ *   pow_r, phase_r  device, CBET_NPHASE doubles each
+ *   xconst, yconst, zconst  main.cu:156-159
+ * plus: the run-time parameters, the workspace and the stream.  Work is enqueued on `stream`
+ * (tabulate node tables -> trace) and the call returns without synchronising; launch errors are
+ * reported through the return value (the reference checks nothing, main.cu:171-175).
+ */
+int cbet_launch_ray_XYZ(int b, unsigned nindices, double *te_data_g, double *r_data_g,
+                        double *ne_data_g, double *edep, double *bbeam_norm, double *beam_norm,
+                        double *pow_r, double *phase_r, double xconst, double yconst,
+                        double zconst, const cbet_params *p, cbet_context *ctx, void *stream);
+
+/*
+ * The two halves of cbet_launch_ray_XYZ, for callers that hold a 3-D plasma state:
+ *   cbet_tabulate_plasma : radial profiles -> ctx node tables (values the reference would
+ *       interpolate at each node, launch_ray_XZ.cu:254-265, 296-305).
+ *   cbet_trace_nodes     : trace using caller-supplied node tables ne3d / kappa3d of nx*ny*nz
+ *       doubles (NULL = the context's own), i.e. an arbitrary, not necessarily spherical, plasma.
+ */
+int cbet_tabulate_plasma(cbet_context *ctx, const cbet_params *p, const double *te_data_g,
+                         const double *r_data_g, const double *ne_data_g, void *stream);
+int cbet_trace_nodes(int b, unsigned nindices, const double *ne3d, const double *kappa3d,
+                     double *edep, const double *bbeam_norm, const double *beam_norm,
+                     const double *pow_r, const double *phase_r, double xconst, double yconst,
+                     double zconst, const cbet_params *p, cbet_context *ctx, void *stream);
+
+/* ---- orchestrator ---------------------------------------------------------------------------- */
+/*
+ * rayTracing (main.cu:96-232): host profiles in, host edep (caller-owned, (nx+2)(ny+2)(nz+2)
+ * doubles) ADDED into.  Uses devices gpus[0..ngpu) (NULL: 0..ngpu-1), one host thread per device;
+ * rays are sharded bundle-interleaved across devices and the per-device grids are combined with
+ * one RCCL all-reduce (replacing the D2H copies and host += loop of main.cu:178-210).
+ * beam_norm: host double[nbeams][3] (the reference reads the global table of omega_beams.h);
+ * NULL = cbet_omega60_beam_norm().  timers (may be NULL) receives {init, tracing, combining,
+ * total} seconds as main.cu:219-231 prints; counters (may be NULL) the summed device counters.
+ */
+int cbet_ray_tracing(const double *te_profile, const double *r_profile, const double *ne_profile,
+                     double *edep, const cbet_params *p, const double *beam_norm, const int *gpus,
+                     int ngpu, double *timers, cbet_counters *counters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CBET_MI355X_H_ */

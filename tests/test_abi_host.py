@@ -1,0 +1,164 @@
+"""Host-side checks of the C-ABI library that need no GPU: it loads, exports every symbol the
+header declares, and its host arithmetic (derived constants, tables, launch list, error paths)
+agrees with the oracle to the last bit."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import DATA, ROOT
+
+
+@pytest.fixture(scope="module")
+def api():
+    from cbet_raytracing_3d_amd import api as a
+    a.lib()
+    return a
+
+
+def test_library_exports_every_declared_symbol(api):
+    hdr = open(os.path.join(ROOT, "include", "cbet_mi355x.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(cbet_[A-Za-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(api.EXPORTS)
+    L = C.CDLL(api.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+
+
+def test_struct_layout_matches_header(api, tmp_path):
+    """ctypes mirrors vs the C header: sizeof and every field offset, asked of gcc."""
+    import subprocess
+    probes = {"cbet_params": api.Params, "cbet_derived": api.Derived, "cbet_counters": api.Counters}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "cbet_mi355x.h"', 'int main(void){']
+    for cname, cls in probes.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines.append('return 0;}')
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = str(tmp_path / "probe")
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe])
+    got = dict(l.split() for l in subprocess.check_output([exe], text=True).splitlines())
+    for cname, cls in probes.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got["%s.%s" % (cname, fname)]) == getattr(cls, fname).offset, (cname, fname)
+    p = api.default_params(100)
+    assert (p.nx, p.nbeams, p.rays_per_zone, p.nprofile, p.max_threads, p.threads_per_block) == \
+        (100, 60, 4, 443, 120000000, 256)
+    assert (p.xmin, p.xmax, p.courant_mult, p.absorption) == (-0.13, 0.13, 0.5, 1)
+
+
+@pytest.mark.parametrize("n", [64, 100, 256, 512])
+def test_derived_bitwise_equal_to_oracle(api, oracle, n):
+    d = api.derive(api.default_params(n))
+    o = oracle.derive(oracle.default_config(n))
+    for f in ("dx", "dy", "dz", "dt", "nt", "zones_spanned", "nrays_x", "nrays_y", "nrays", "omega",
+              "ncrit", "uray_mult", "xconst", "yconst", "zconst", "threads_per_beam", "nindices",
+              "grid_y", "edep_size"):
+        assert getattr(d, f) == getattr(o, f), f
+
+
+def test_host_tables_bitwise_equal_to_oracle(api, oracle, inputs):
+    bn = inputs[0]
+    ph, pw = api.host_power_table()
+    oph, opw = oracle.power_table()
+    assert np.array_equal(ph, oph) and np.array_equal(pw, opw)
+    assert np.array_equal(api.host_beam_trig(bn), oracle.beam_trig(bn))
+
+
+def test_beam_table_and_profiles(api, inputs):
+    bn, r, ne, te = inputs
+    assert np.array_equal(api.omega60_beam_norm(), bn)
+    assert np.allclose(np.linalg.norm(bn, axis=1), 1.0, atol=1e-8)
+    r2, ne2, te2 = api.load_s83177()
+    assert np.array_equal(r2, r) and np.array_equal(ne2, ne) and np.array_equal(te2, te)
+    # exactly 443 rows are read (def.cuh:33); the file's 444th row (r=0.343967, 0) is never used
+    assert len(open(os.path.join(DATA, "s83177_ne.txt")).read().split()) == 888
+    with pytest.raises(api.CbetError) as ei:
+        api.read_profile(os.path.join(DATA, "s83177_ne.txt"), 445)
+    assert ei.value.code == api.EINVAL
+
+
+@pytest.mark.parametrize("n", [64, 100])
+def test_live_list_is_the_reference_ray_set(api, oracle, inputs, n):
+    bn = inputs[0]
+    p = api.default_params(n)
+    slots = api.live_ray_list(p)
+    live = slots[slots >= 0]
+    d = api.derive(p)
+    assert len(slots) % 64 == 0 and all((slots[k:k + 64] >= 0).any() for k in range(0, len(slots), 64))
+    assert len(live) == d.nlive_rays and len(set(live.tolist())) == len(live)
+    cfg = oracle.default_config(n)
+    L = oracle.lib()
+    want = [i for i in range(d.nrays)
+            if L.cbet_oracle_id_is_traced(C.byref(cfg), i) and oracle.launch_point(cfg, bn, 7, i)[0]]
+    assert sorted(live.tolist()) == want
+    if n == 100:
+        assert len(live) == 15102 and d.ntraced_ids == 19456
+
+
+def test_bundles_are_compact_patches(api, oracle, inputs):
+    """One bundle = an 8x8-ray patch: its launch points span at most 2 cells in-plane, and only
+    patches on the beam edge have holes."""
+    bn = inputs[0]
+    p = api.default_params(256)
+    d = api.derive(p)
+    slots = api.live_ray_list(p)
+    fill = (slots.reshape(-1, 64) >= 0).sum(1)
+    assert (fill == 64).mean() > 0.9 and fill.sum() == d.nlive_rays == 98872
+    assert d.nlive_rays / len(slots) > 0.95           # idle lanes from holes: < 5 %
+    cfg = oracle.default_config(256)
+    for k in (0, 640, 64 * 700, len(slots) - 64):
+        ids = slots[k:k + 64]
+        pts = np.array([oracle.launch_point(cfg, bn, 11, int(i))[1][:3] for i in ids[ids >= 0]])
+        assert np.ptp(pts, axis=0).max() <= 2.0 * d.dx * 1.0001
+
+
+def test_shard_plan_partitions_the_work(api):
+    p = api.default_params(64)
+    nb = 3
+    full_b, full_i = api.shard_items(p, nb, 0, 1)
+    assert len(full_i) == nb * api.derive(p).nlive_rays
+    seen = []
+    for s in range(4):
+        b, i = api.shard_items(p, nb, s, 4)
+        seen.append(np.stack([b, i], 1))
+    allp = np.concatenate(seen)
+    assert len(allp) == len(full_i)
+    assert len({(int(a), int(b)) for a, b in allp}) == len(full_i)
+    sizes = [len(s) for s in seen]
+    assert max(sizes) - min(sizes) <= 0.05 * max(sizes)
+
+
+def test_error_paths_without_a_gpu(api):
+    p = api.default_params(100)
+    bad = p.copy(nx=2)
+    with pytest.raises(api.CbetError) as ei:
+        api.derive(bad)
+    assert ei.value.code == api.EINVAL
+    with pytest.raises(api.CbetError) as ei:
+        api.derive(p.copy(shard_count=4, shard_index=4))
+    assert ei.value.code == api.EINVAL
+    with pytest.raises(api.CbetError) as ei:
+        api.derive(p.copy(nx=1400, ny=1400, nz=1400))   # (n+2)^3 >= 2^31: 32-bit node tags
+    assert ei.value.code == api.EINVAL
+    with pytest.raises(api.CbetError) as ei:           # multi_gpu.cpp:45-48
+        api.moveToAndFromGPU(np.zeros(4), np.zeros(4), 32, -1)
+    assert ei.value.code == api.ENODEVICE
+
+
+def test_product_does_not_import_the_oracle():
+    """The shipped path must never route through oracle/ (only tests, smoke and the bench's
+    cpu_baseline leg may)."""
+    pkg = os.path.join(ROOT, "cbet_raytracing_3d_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "cbet_oracle" not in text and "import oracle" not in text, f

@@ -1,0 +1,286 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the golden fixtures.
+
+Tolerance: BASELINE.json asks for <= 1e-4 max rel-err (metric of SURVEY.md 8(c), conftest.parity_err).
+The kernels are built with -ffp-contract=off so each ray's arithmetic is the oracle's operation
+sequence; what remains is fp64 summation order, so the tests hold the path to PARITY_TOL = 1e-9
+(observed ~1e-13) -- five orders tighter than the stated bound -- and to EXACT ray-step counts.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, NCPU, parity_err
+
+pytestmark = pytest.mark.gpu
+
+PARITY_TOL = 1e-9          # asserted;  BASELINE.json's bound is 1e-4
+VARIANTS = [1, 2]          # CBET_KERNEL_GLOBAL_ATOMICS, CBET_KERNEL_LDS_COMBINE
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "the gpu tests need a HIP device"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def api():
+    from cbet_raytracing_3d_amd import api as a
+    a.lib()   # raises if the HIP library was not built -- no fallback
+    return a
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return json.load(open(os.path.join(GOLDEN, "golden.json")))
+
+
+def make_tracer(api, inputs, n, **kw):
+    from cbet_raytracing_3d_amd.tracer import RayTracer
+    bn, r, ne, te = inputs
+    beams = kw.pop("beams", None)
+    ne = kw.pop("ne", ne)
+    te = kw.pop("te", te)
+    p = api.default_params(n, **kw)
+    if beams is not None:
+        bn = bn[beams]
+        p.nbeams = len(beams)
+    return RayTracer(p, r, ne, te, beam_norm=bn)
+
+
+def run(tr, torch, **kw):
+    e = tr.new_grid()
+    tr.counters(reset=True)
+    tr.launch(e, **kw)
+    c = tr.counters(reset=True)
+    return e.cpu().numpy(), c
+
+
+def test_helpers_roundtrip_and_errors(api, torch_cuda):
+    """multi_gpu.cpp:3-28, 44-59 semantics through the ABI."""
+    host = np.arange(1000, dtype=np.float64)
+    back = np.zeros_like(host)
+    d = api.safeGPUAlloc(host.nbytes, 0)
+    assert d
+    api.moveToAndFromGPU(d, host, host.nbytes, 0)      # H2D, direction inferred
+    d2 = api.safeGPUAlloc(host.nbytes, 0)
+    api.moveToAndFromGPU(d2, d, host.nbytes, 0)        # D2D
+    api.moveToAndFromGPU(back, d2, host.nbytes, 0)     # D2H
+    assert np.array_equal(back, host)
+    api.gpuFree(d, 0)
+    api.gpuFree(d2, 0)
+    with pytest.raises(api.CbetError) as ei:           # free < size guard
+        api.safeGPUAlloc(1 << 50, 0)
+    assert ei.value.code == api.ENOMEM
+    with pytest.raises(api.CbetError) as ei:
+        api.moveToAndFromGPU(back, host, 8, -1)
+    assert ei.value.code == api.ENODEVICE
+    with pytest.raises(api.CbetError) as ei:
+        api.safeGPUAlloc(8, 999)
+    assert ei.value.code == api.ENODEVICE
+
+
+def test_node_tables_match_oracle(api, oracle, inputs, torch_cuda):
+    bn, r, ne, te = inputs
+    tr = make_tracer(api, inputs, 48)
+    e = tr.new_grid()
+    tr.launch(e)
+    torch_cuda.cuda.synchronize()
+    ne3d, kap = tr.node_tables()
+    one3d, okap = oracle.node_tables(oracle.default_config(48), r, ne, te)
+    assert np.abs(ne3d / one3d - 1).max() < 1e-15 and np.abs(kap / okap - 1).max() < 1e-14
+    exact = (ne3d == one3d).mean(), (kap == okap).mean()
+    print("node tables bitwise-equal fraction ne3d=%.6f kappa=%.6f" % exact)
+    tr.close()
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_config1_two_beams_uniform_plasma(api, oracle, inputs, torch_cuda, golden, variant):
+    """BASELINE config 1: 2 crossing beams, 64^3 uniform plasma, refraction only, vs the serial CPU loop."""
+    bn, r, _, _ = inputs
+    g = golden["config1_64"]
+    d = api.derive(api.default_params(64))
+    ne_u, te_u = np.full(443, g["ne_over_ncrit"] * d.ncrit), np.full(443, g["te"])
+    tr = make_tracer(api, inputs, 64, beams=g["beams"], absorption=0, ne=ne_u, te=te_u)
+    e, c = run(tr, torch_cuda, kernel_variant=variant)
+    assert c.ray_steps == g["ray_steps"]
+    cfg = oracle.default_config(64, nbeams=2, absorption=0)
+    oe, osteps = oracle.trace(cfg, bn[g["beams"]].copy(), r, ne_u, te_u, nthreads=1)   # serial ray loop
+    assert osteps == c.ray_steps
+    assert parity_err(e, oe) < PARITY_TOL
+    assert np.count_nonzero(e) == g["nonzero"]
+    planes = np.load(os.path.join(GOLDEN, "planes_cfg1_64.npz"))
+    assert parity_err(e[33], planes["yz"]) < PARITY_TOL
+    tr.close()
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_full_grid_parity_64(api, oracle, inputs, torch_cuda, golden, variant):
+    """60 beams, s83177, 64^3: every one of the 66^3 cells against the oracle."""
+    bn, r, ne, te = inputs
+    tr = make_tracer(api, inputs, 64)
+    e, c = run(tr, torch_cuda, kernel_variant=variant)
+    oe, osteps, per_beam = oracle.trace(oracle.default_config(64), bn, r, ne, te, nthreads=NCPU,
+                                        want_per_beam=True)
+    g = golden["cases"][0]
+    assert c.ray_steps == osteps == g["ray_steps"] == 30712072
+    assert c.rays_traced == 60 * tr.derived.nlive_rays
+    err = parity_err(e, oe)
+    print("64^3 variant %d: parity err %.3e, global atomics per step %.3f" %
+          (variant, err, c.global_atomics / c.ray_steps))
+    assert err < PARITY_TOL
+    assert np.array_equal(e == 0, oe == 0)              # the over-critical core stays exactly 0
+    assert np.array_equal(e < 0, oe < 0)
+    tr.close()
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_truth_100_golden(api, oracle, inputs, torch_cuda, golden, variant, tmp_path):
+    """BASELINE config 2 (the reference's `make test` case): golden planes, scalar known answers
+    and the byte-exact 6-digit text dump (Makefile:14-17)."""
+    tr = make_tracer(api, inputs, 100)
+    e, c = run(tr, torch_cuda, kernel_variant=variant)
+    g = golden["cases"][1]
+    assert c.ray_steps == g["ray_steps"] == 124789870
+    assert c.rays_traced == 60 * 15102
+    assert np.count_nonzero(e) == g["nonzero"] == 1055570
+    assert int((e < 0).sum()) == 1 and e[101, 7, 0] == pytest.approx(-7512.4896951, rel=1e-10)
+    assert e.sum() == pytest.approx(g["sum"], rel=1e-12)
+    assert e.max() == pytest.approx(g["max"], rel=1e-12)
+    assert e[1, 1, 1] == pytest.approx(668336.05188607727, rel=1e-12)
+    assert e[51, 51, 90] == pytest.approx(23295164142.968483, rel=1e-12)
+    assert e[51, 51, 51] == 0.0
+    planes = np.load(os.path.join(GOLDEN, "planes_100.npz"))
+    for name, got in (("yz", e[51]), ("xz", e[:, 51]), ("xy", e[:, :, 51]), ("face_x0", e[0]),
+                      ("face_z0", e[:, :, 0])):
+        assert parity_err(got, planes[name]) < PARITY_TOL, name
+    path = str(tmp_path / "edep.txt")
+    assert oracle.write_text(e, path) == g["text_bytes"] == 12544620
+    assert hashlib.md5(open(path, "rb").read()).hexdigest() == g["text_md5"]
+    tr.close()
+
+
+def test_sharding_and_beam_independence(api, inputs, torch_cuda):
+    """edep(all) == sum over shards == sum over beams, to summation-order rounding."""
+    tr = make_tracer(api, inputs, 64)
+    full, c = run(tr, torch_cuda)
+    parts = tr.new_grid()
+    steps = 0
+    for s in range(3):
+        tr.launch(parts, shard_index=s, shard_count=3)
+        steps += tr.counters(reset=True).ray_steps
+    assert steps == c.ray_steps
+    assert parity_err(parts.cpu().numpy(), full) < 1e-11
+    by_beam = tr.new_grid()
+    for lo in range(0, 60, 20):
+        tr.launch(by_beam, beam_lo=lo, beam_hi=lo + 20)
+    assert parity_err(by_beam.cpu().numpy(), full) < 1e-11
+    # the reference's own split rule: b-th block of nbeams/ngpus beams (launch_ray_XZ.cu:123)
+    p = tr.params.copy(ngpus=2, beam_lo=0, beam_hi=0)
+    halves = tr.new_grid()
+    d = tr.derived
+    stream = torch_cuda.cuda.current_stream().cuda_stream
+    for b in range(2):
+        api.launch_ray_XYZ(b, d.nindices, tr.d_te, tr.d_r, tr.d_ne, halves, tr.d_bbeam_norm,
+                           tr.d_beam_norm, tr.d_pow_r, tr.d_phase_r, d.xconst, d.yconst, d.zconst,
+                           p, ctx=tr.ctx, stream=stream)
+    assert parity_err(halves.cpu().numpy(), full) < 1e-11
+    tr.close()
+
+
+def test_accumulates_into_edep_and_window_sizes(api, inputs, torch_cuda):
+    """edep is added into, never cleared (launch_ray_XZ.cu:341-348); both LDS window sizes agree."""
+    tr = make_tracer(api, inputs, 64, nbeams=6)
+    a, _ = run(tr, torch_cuda, kernel_variant=2, lds_window_log2=3)
+    b, _ = run(tr, torch_cuda, kernel_variant=2, lds_window_log2=4)
+    assert parity_err(b, a) < 1e-11
+    e = tr.new_grid()
+    tr.launch(e)
+    tr.launch(e)
+    assert parity_err(e.cpu().numpy(), 2 * a) < 1e-11
+    tr.close()
+
+
+def test_device_trig_fallback_is_close(api, inputs, torch_cuda):
+    """bbeam_norm == NULL evaluates acos/atan2/cos/sin on the device (launch_ray_XZ.cu:99-111 as
+    written); device libm may differ from the host's in the last bit, hence 1e-4, not 1e-9."""
+    tr = make_tracer(api, inputs, 64, nbeams=8)
+    a, ca = run(tr, torch_cuda)
+    b, cb = run(tr, torch_cuda, use_host_trig=False)
+    assert abs(int(ca.ray_steps) - int(cb.ray_steps)) <= 1e-4 * ca.ray_steps
+    assert abs(b.sum() / a.sum() - 1) < 1e-6
+    tr.close()
+
+
+def test_invalid_launches_fail_loudly(api, inputs, torch_cuda):
+    tr = make_tracer(api, inputs, 32, nbeams=2)
+    e = tr.new_grid()
+    d = tr.derived
+    args = (tr.d_te, tr.d_r, tr.d_ne, e, tr.d_bbeam_norm, tr.d_beam_norm, tr.d_pow_r, tr.d_phase_r,
+            d.xconst, d.yconst, d.zconst)
+    with pytest.raises(api.CbetError) as ei:                       # geometry mismatch with workspace
+        api.launch_ray_XYZ(0, d.nindices, *args, api.default_params(48, nbeams=2), ctx=tr.ctx)
+    assert ei.value.code == api.EINVAL
+    with pytest.raises(api.CbetError):                             # wrong nindices
+        api.launch_ray_XYZ(0, d.nindices + 1, *args, tr.params, ctx=tr.ctx)
+    with pytest.raises(api.CbetError):                             # beam range outside the table
+        api.launch_ray_XYZ(0, d.nindices, *args, tr.params.copy(beam_lo=1, beam_hi=3), ctx=tr.ctx)
+    with pytest.raises(api.CbetError):
+        api.launch_ray_XYZ(0, d.nindices, *args, tr.params.copy(kernel_variant=77), ctx=tr.ctx)
+    api.launch_ray_XYZ(0, 0, *args, tr.params, ctx=tr.ctx)         # nindices = 0: ray loop skipped
+    torch_cuda.cuda.synchronize()
+    assert float(e.abs().sum()) == 0.0
+    api.launch_ray_XYZ(0, d.nindices, *args, tr.params, ctx=None)  # default per-device workspace
+    torch_cuda.cuda.synchronize()
+    assert float(e.sum()) > 0
+    tr.close()
+
+
+def test_ray_tracing_orchestrator(api, oracle, inputs, torch_cuda):
+    """cbet_ray_tracing (rayTracing(), main.cu:96-232) on one device: host arrays in, edep += out."""
+    bn, r, ne, te = inputs
+    p = api.default_params(48, nbeams=10)
+    edep = np.full((50, 50, 50), 1.0)                   # pre-existing content must be kept (+=)
+    timers, cnt = api.ray_tracing(te, r, ne, edep, p, beam_norm=bn[:10])
+    oe, osteps = oracle.trace(oracle.default_config(48, nbeams=10), bn[:10].copy(), r, ne, te, nthreads=NCPU)
+    assert cnt.ray_steps == osteps
+    assert parity_err(edep - 1.0, oe) < 1e-9
+    assert timers["total"] >= timers["tracing"] > 0
+
+
+def test_nonuniform_grid_and_rays_per_zone(api, oracle, inputs, torch_cuda):
+    """Ragged case: nx != ny != nz and rays_per_zone = 3 (patches no longer align with zones)."""
+    bn, r, ne, te = inputs
+    from cbet_raytracing_3d_amd.tracer import RayTracer
+    p = api.default_params(40, nbeams=4, rays_per_zone=3)
+    p.ny, p.nz = 48, 36
+    tr = RayTracer(p, r, ne, te, beam_norm=bn[[1, 12, 33, 58]])
+    e, c = run(tr, torch_cuda)
+    cfg = oracle.default_config(40, nbeams=4, rays_per_zone=3)
+    cfg.ny, cfg.nz = 48, 36
+    oe, osteps = oracle.trace(cfg, bn[[1, 12, 33, 58]].copy(), r, ne, te, nthreads=NCPU)
+    assert c.ray_steps == osteps
+    assert parity_err(e, oe) < PARITY_TOL
+    tr.close()
+
+
+def test_full_size_256_properties(api, inputs, torch_cuda):
+    """BASELINE config 3 size.  The oracle needs minutes here, so check the size-independent facts:
+    SURVEY.md 8(c) known answers at 256^3, energy bookkeeping and variant agreement."""
+    tr = make_tracer(api, inputs, 256)
+    e2, c2 = run(tr, torch_cuda, kernel_variant=2)
+    assert c2.ray_steps == 2123497670
+    assert c2.rays_traced == 60 * 98872
+    assert e2.sum() == pytest.approx(1.0076068555e19, rel=1e-10)
+    assert e2.max() == pytest.approx(4.0037106759e13, rel=1e-10)
+    assert np.count_nonzero(e2) == 17053618 and e2.size == 17173512
+    e1, c1 = run(tr, torch_cuda, kernel_variant=1)
+    assert c1.ray_steps == c2.ray_steps and c1.global_atomics == 8 * c1.ray_steps
+    assert parity_err(e2, e1) < 1e-10
+    print("256^3: LDS-combine global atomics per ray-step = %.3f (global variant: 8)" %
+          (c2.global_atomics / c2.ray_steps))
+    tr.close()

@@ -1,0 +1,64 @@
+"""The N>1 path on CPU: world_size-2 gloo.  Each rank takes the product's shard plan
+(api.shard_items = the kernel's bundle -> shard rule), traces its share with the oracle standing in
+for the device, and the grids are combined with tracer.allreduce_grid -- the same call the GPU
+ranks make over RCCL.  The combined grid must equal the unsharded one."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_inputs, parity_err
+
+
+def _worker(rank, world, port, n, nbeams, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cbet_raytracing_3d_amd import api
+        from cbet_raytracing_3d_amd.tracer import allreduce_grid, shard_of_rank
+        from oracle import cbet_oracle as O
+        bn, r, ne, te = load_inputs()
+        p = api.default_params(n, nbeams=nbeams)
+        si, sc = shard_of_rank(rank, world)
+        beams, ids = api.shard_items(p, nbeams, si, sc)
+        cfg = O.default_config(n, nbeams=nbeams)
+        e, steps = O.trace_list(cfg, bn[:nbeams].copy(), r, ne, te, beams, ids, nthreads=2)
+        t = torch.from_numpy(e)
+        allreduce_grid(t)
+        total = torch.tensor([steps, len(ids)], dtype=torch.int64)
+        dist.all_reduce(total)
+        if rank == 0:
+            np.save(os.path.join(out_dir, "edep.npy"), t.numpy())
+            np.save(os.path.join(out_dir, "total.npy"), total.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_pass_equals_unsharded(tmp_path, oracle, world):
+    n, nbeams = 32, 5
+    port = 29500 + (os.getpid() % 500) + world
+    mp.spawn(_worker, args=(world, port, n, nbeams, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / "edep.npy")
+    steps, nrays = np.load(tmp_path / "total.npy")
+    bn, r, ne, te = load_inputs()
+    cfg = oracle.default_config(n, nbeams=nbeams)
+    want, wsteps = oracle.trace(cfg, bn[:nbeams].copy(), r, ne, te, nthreads=4)
+    assert steps == wsteps
+    assert parity_err(got, want) < 1e-11
+    from cbet_raytracing_3d_amd import api
+    assert nrays == nbeams * api.derive(api.default_params(n, nbeams=nbeams)).nlive_rays
+
+
+def test_allreduce_is_noop_without_process_group():
+    from cbet_raytracing_3d_amd.tracer import allreduce_grid, shard_of_rank
+    t = torch.ones(4, dtype=torch.float64)
+    assert allreduce_grid(t) is t and float(t.sum()) == 4.0
+    assert shard_of_rank(3, 8) == (3, 8)
+    with pytest.raises(ValueError):
+        shard_of_rank(8, 8)
