@@ -26,6 +26,9 @@ int fail(int code, const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
+    // HIP keeps the last error sticky until read; a reported failure must not leak into the
+    // caller's (or torch's) next hipGetLastError() check.
+    if (code == CBET_EHIP || code == CBET_ENODEVICE || code == CBET_ENOMEM) (void)hipGetLastError();
     return code;
 }
 

@@ -206,11 +206,12 @@ __device__ __forceinline__ int wave_sum(int v)
 // flat haloed index.  All 64 lanes of the wave run this in lock step (one wave per workgroup, so
 // no other wave touches the window); LDS operations of one wave execute in program order.
 //   fast path : read the 8 tags; where tag == node, ds_add_f64 the weight.
-//   slow path : per corner, retry until done: re-read the tag; on a match add; otherwise CAS the
-//               tag to this node -- exactly one lane per slot wins, swaps its weight in as the new
-//               accumulator value and writes the old (tag, sum) back to HBM with one atomic.
-// Every fast-path add precedes every slow-path swap in program order, so a swapped-out sum holds
-// all adds made under the old tag.
+//   slow path : per corner, retry until done, each round in two ordered phases: (1) re-read the
+//               tag, lanes that match add; (2) the rest CAS the tag to their node -- exactly one
+//               lane per slot wins, swaps its weight in as the new accumulator value and writes
+//               the old (tag, sum) back to HBM with one atomic.
+// Invariant: an add under tag T is always issued before the instruction that replaces T, so a
+// swapped-out sum holds every add made under the old tag and nothing else.
 // ---------------------------------------------------------------------------------------------
 template <int WL>
 struct LdsWindow {
@@ -269,34 +270,44 @@ __device__ __forceinline__ void lds_deposit8(LdsWindow<WL> &win, bool pending, c
         }
     }
     if (!__any(miss != 0)) return;
+    __builtin_amdgcn_wave_barrier();  // every fast-path add is issued before any slot changes owner
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         bool pend = (miss >> c) & 1u;
         while (__any(pend)) {
+            unsigned t = 0;
+            if (pend)
+                t = __hip_atomic_load(&win.tag[slot[c]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // phase 1: lanes whose node owns the slot add.  This must complete, for ALL lanes,
+            // before phase 2 lets any lane hand the slot to another node -- hence two separate
+            // statements with a wave barrier between them, not an if/else whose block order the
+            // compiler chooses.
+            if (pend && t == node[c]) {
+                win.add(slot[c], w[c]);
+                pend = false;
+            }
+            __builtin_amdgcn_wave_barrier();
+            // phase 2: the others try to claim the slot; one lane per slot wins the CAS, swaps its
+            // weight in as the new sum and writes the previous owner's sum back to HBM.  Losers
+            // (and lanes whose node just became the owner) go round again.
             if (pend) {
-                const unsigned t =
-                    __hip_atomic_load(&win.tag[slot[c]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (t == node[c]) {
-                    win.add(slot[c], w[c]);
-                    pend = false;
-                } else {
-                    unsigned expect = t;
-                    const bool won = __hip_atomic_compare_exchange_strong(
-                        &win.tag[slot[c]], &expect, node[c], __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                unsigned expect = t;
+                const bool won = __hip_atomic_compare_exchange_strong(
+                    &win.tag[slot[c]], &expect, node[c], __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                    __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (won) {
+                    const unsigned long long old = __hip_atomic_exchange(
+                        reinterpret_cast<unsigned long long *>(&win.val[slot[c]]),
+                        (unsigned long long)__double_as_longlong(w[c]), __ATOMIC_RELAXED,
                         __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (won) {
-                        const unsigned long long old = __hip_atomic_exchange(
-                            reinterpret_cast<unsigned long long *>(&win.val[slot[c]]),
-                            (unsigned long long)__double_as_longlong(w[c]), __ATOMIC_RELAXED,
-                            __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (t != kEmptyTag) {
-                            global_add(&edep[t], __longlong_as_double((long long)old));
-                            ++n_evict;
-                        }
-                        pend = false;
+                    if (t != kEmptyTag) {
+                        global_add(&edep[t], __longlong_as_double((long long)old));
+                        ++n_evict;
                     }
+                    pend = false;
                 }
             }
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }

@@ -1,0 +1,28 @@
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cbet_raytracing_3d_amd import api
+from cbet_raytracing_3d_amd.tracer import RayTracer
+from oracle import cbet_oracle as O
+
+def perr(a,b):
+    fl=1e-9*np.abs(b).max(); return (np.abs(a-b)/np.maximum(np.abs(b),fl))
+
+n, nb = int(sys.argv[1]) if len(sys.argv)>1 else 48, int(sys.argv[2]) if len(sys.argv)>2 else 8
+r, ne, te = api.load_s83177(); bn = api.omega60_beam_norm()[:nb]
+tr = RayTracer(api.default_params(n, nbeams=nb), r, ne, te, beam_norm=bn)
+want, steps = O.trace(O.default_config(n, nbeams=nb), bn.copy(), r, ne, te, nthreads=16)
+ne3d,kap = tr.node_tables() if False else (None,None)
+for v, w in ((1,0),(2,3),(2,4)):
+    e = tr.new_grid(); tr.counters(reset=True)
+    tr.launch(e, kernel_variant=v, lds_window_log2=w or None)
+    c = tr.counters(reset=True); g = e.cpu().numpy()
+    pe = perr(g, want); i = np.unravel_index(pe.argmax(), pe.shape)
+    print("variant", v, "w", w, "steps", c.ray_steps, steps, "rays", c.rays_traced, "atomics", c.global_atomics,
+          "evict", c.lds_evictions, "err %.3e"%pe.max(), "at", i, g[i], want[i],
+          "sum ratio %.15f"%(g.sum()/want.sum()), "nbad", int((pe>1e-9).sum()), "of", pe.size)
+    bad = np.argwhere(pe>1e-9)
+    if len(bad): print("  bad bbox", bad.min(0), bad.max(0), " sample diffs", [(tuple(b), g[tuple(b)]-want[tuple(b)]) for b in bad[:5]])
+a,b = tr.node_tables()
+o1,o2 = O.node_tables(O.default_config(n, nbeams=nb), r, ne, te)
+print("tables: ne3d max rel", np.abs(a/o1-1).max(), "bitwise frac", (a==o1).mean(), " kap", np.abs(b/o2-1).max(), (b==o2).mean())

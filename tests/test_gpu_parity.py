@@ -49,6 +49,8 @@ def make_tracer(api, inputs, n, **kw):
     if beams is not None:
         bn = bn[beams]
         p.nbeams = len(beams)
+    else:
+        bn = bn[:p.nbeams]
     return RayTracer(p, r, ne, te, beam_norm=bn)
 
 
