@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--n", type=int, default=256, help="grid nodes per axis (BASELINE config 3: 256)")
     ap.add_argument("--variant", type=int, default=0, help="cbet_params.kernel_variant (0 = default)")
     ap.add_argument("--window", type=int, default=0, help="cbet_params.lds_window_log2 (0 = default)")
+    ap.add_argument("--copies", type=int, default=-1, help="cbet_params.lds_copies_log2 (-1 = default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -66,7 +67,8 @@ def main():
     n = args.n
     r, ne, te = api.load_s83177()
     bn = api.omega60_beam_norm()
-    p = api.default_params(n, kernel_variant=args.variant, lds_window_log2=args.window)
+    p = api.default_params(n, kernel_variant=args.variant, lds_window_log2=args.window,
+                           lds_copies_log2=args.copies)
     tr = RayTracer(p, r, ne, te, beam_norm=bn)
     edep = tr.new_grid()
     si, sc = shard_of_rank(rank, world)

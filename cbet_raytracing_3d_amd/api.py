@@ -20,7 +20,7 @@ DATA_DIR = os.path.join(_PKG, "data")
 
 OK, EINVAL, EHIP, ENOMEM, ENODEVICE, ECOMM = 0, -1, -2, -3, -4, -5
 NPHASE = 2001
-KERNEL_DEFAULT, KERNEL_GLOBAL_ATOMICS, KERNEL_LDS_COMBINE = 0, 1, 2
+KERNEL_DEFAULT, KERNEL_GLOBAL_ATOMICS, KERNEL_LDS_COMBINE, KERNEL_LDS_WINDOW = 0, 1, 2, 3
 
 
 class CbetError(RuntimeError):
@@ -43,8 +43,8 @@ class Params(C.Structure):
         ("ngpus", C.c_int),
         ("beam_lo", C.c_int), ("beam_hi", C.c_int),
         ("shard_index", C.c_int), ("shard_count", C.c_int),
-        ("kernel_variant", C.c_int), ("lds_window_log2", C.c_int),
-        ("reserved", C.c_int * 6),
+        ("kernel_variant", C.c_int), ("lds_window_log2", C.c_int), ("lds_copies_log2", C.c_int),
+        ("reserved", C.c_int * 5),
     ]
 
     def copy(self, **overrides):
@@ -83,6 +83,7 @@ EXPORTS = [
     "cbet_safeGPUAlloc", "cbet_moveToAndFromGPU", "cbet_gpuFree",
     "cbet_context_create", "cbet_context_destroy", "cbet_context_counters", "cbet_context_tables",
     "cbet_launch_ray_XYZ", "cbet_tabulate_plasma", "cbet_trace_nodes", "cbet_ray_tracing",
+    "cbet_write_text", "cbet_edep_average",
 ]
 
 _lib = None
@@ -122,6 +123,9 @@ def lib():
                                    C.c_double, C.c_double, C.c_double, C.POINTER(Params), vp, vp]
     L.cbet_ray_tracing.argtypes = [dp, dp, dp, dp, C.POINTER(Params), dp, ip, C.c_int, dp,
                                    C.POINTER(Counters)]
+    L.cbet_write_text.argtypes = [dp, C.c_int, C.c_int, C.c_int, C.c_char_p]
+    L.cbet_write_text.restype = C.c_longlong
+    L.cbet_edep_average.argtypes = [dp, dp, C.c_int, C.c_int, C.c_int]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = the library is older than the header
     _lib = L
@@ -328,3 +332,23 @@ def ray_tracing(te_profile, r_profile, ne_profile, edep, params, beam_norm=None,
                                   _dptr(bn) if bn is not None else None, garr, ngpu, _dptr(timers),
                                   C.byref(cnt)))
     return dict(zip(("init", "tracing", "combining", "total"), timers.tolist())), cnt
+
+
+# ---- output stage ------------------------------------------------------------------------------
+def write_text(edep, path):
+    """main.cu:6-22 `-D PRINT` rendering (truth_100's format) of a host (d0,d1,d2) array."""
+    e = np.ascontiguousarray(edep, dtype=np.float64)
+    n = lib().cbet_write_text(_dptr(e), e.shape[0], e.shape[1], e.shape[2],
+                              os.fsencode(path) if path is not None else None)
+    if n < 0:
+        _check(int(n))
+    return int(n)
+
+
+def edep_average(edep):
+    """main.cu:334-349: 27-point average of the haloed grid -> (nx, ny, nz)."""
+    e = np.ascontiguousarray(edep, dtype=np.float64)
+    nx, ny, nz = (d - 2 for d in e.shape)
+    out = np.zeros((nx, ny, nz))
+    _check(lib().cbet_edep_average(_dptr(e), _dptr(out), nx, ny, nz))
+    return out

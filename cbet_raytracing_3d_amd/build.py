@@ -13,8 +13,8 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcbet_mi355x.so")
-SOURCES = ["cbet_kernels.hip", "cbet_abi.cpp", "cbet_host.cpp"]
-HEADERS = [os.path.join(CSRC, "cbet_device.h"), os.path.join(ROOT, "include", "cbet_mi355x.h"),
+SOURCES = ["cbet_kernels.hip", "cbet_abi.cpp", "cbet_host.cpp", "cbet_output.cpp"]
+HEADERS = [os.path.join(CSRC, "cbet_device.h"), os.path.join(CSRC, "cbet_relocate.h"), os.path.join(ROOT, "include", "cbet_mi355x.h"),
            os.path.join(ROOT, "include", "cbet_omega_beams.h")]
 
 # -ffp-contract=off: a ray's fp64 arithmetic must be the reference's operation sequence (no fused
@@ -34,7 +34,8 @@ def is_stale():
     if not os.path.exists(LIB_PATH):
         return True
     built = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS + [os.path.abspath(__file__)]
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS + [os.path.abspath(__file__),
+                                                                os.path.join(ROOT, "tools", "cbet_gpu.cpp")]
     return any(os.path.getmtime(d) > built for d in deps)
 
 
@@ -48,7 +49,22 @@ def build(force=False, verbose=False, extra_flags=()):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    build_cli(verbose)
     return LIB_PATH
+
+
+CLI_PATH = os.path.join(PKG, "lib", "cbet-gpu")
+
+
+def build_cli(verbose=False):
+    """tools/cbet_gpu.cpp -> lib/cbet-gpu: the main.cu-shaped driver, linked against the C ABI only."""
+    cmd = ["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tools", "cbet_gpu.cpp"), "-o", CLI_PATH,
+           "-L", LIB_DIR, "-lcbet_mi355x", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + "/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return CLI_PATH
 
 
 if __name__ == "__main__":

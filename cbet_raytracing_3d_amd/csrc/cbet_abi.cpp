@@ -211,6 +211,7 @@ int cbet_params_default(cbet_params *p, int n)
     p->shard_index = 0;
     p->shard_count = 1;
     p->kernel_variant = CBET_KERNEL_DEFAULT;
+    p->lds_copies_log2 = -1;
     return CBET_OK;
 }
 
@@ -476,11 +477,14 @@ int cbet_trace_nodes(int b, unsigned nindices, const double *ne3d, const double 
     if (beam_hi == beam_lo || ctx->nlive == 0) return CBET_OK;
 
     int variant = p->kernel_variant;
-    if (variant == CBET_KERNEL_DEFAULT) variant = CBET_KERNEL_LDS_COMBINE;
-    if (variant != CBET_KERNEL_GLOBAL_ATOMICS && variant != CBET_KERNEL_LDS_COMBINE)
+    if (variant == CBET_KERNEL_DEFAULT) variant = CBET_KERNEL_LDS_WINDOW;
+    if (variant != CBET_KERNEL_GLOBAL_ATOMICS && variant != CBET_KERNEL_LDS_COMBINE &&
+        variant != CBET_KERNEL_LDS_WINDOW)
         return fail(CBET_EINVAL, "unknown kernel_variant %d", p->kernel_variant);
     int wl = p->lds_window_log2 ? p->lds_window_log2 : 3;
     if (wl != 3 && wl != 4) return fail(CBET_EINVAL, "lds_window_log2 must be 3 or 4");
+    int rl = p->lds_copies_log2 < 0 ? 1 : p->lds_copies_log2;  // auto: 2 copies (measured best)
+    if (rl > 2) return fail(CBET_EINVAL, "lds_copies_log2 must be -1 (auto) or 0..2");
 
     const cbet_derived &d = ctx->d;
     TraceArgs a{};
@@ -512,7 +516,7 @@ int cbet_trace_nodes(int b, unsigned nindices, const double *ne3d, const double 
 
     DeviceGuard guard;
     CBET_HIP(hipSetDevice(ctx->gpu));
-    CBET_HIP(launch_trace(a, variant, wl, (hipStream_t)stream));
+    CBET_HIP(launch_trace(a, variant, wl, rl, (hipStream_t)stream));
     return CBET_OK;
 }
 

@@ -67,7 +67,7 @@ struct TraceArgs {
 };
 
 hipError_t launch_tabulate(const TabulateArgs &a, hipStream_t stream);
-hipError_t launch_trace(const TraceArgs &a, int variant, int window_log2, hipStream_t stream);
+hipError_t launch_trace(const TraceArgs &a, int variant, int window_log2, int copies_log2, hipStream_t stream);
 
 }  // namespace cbet
 #endif

@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include "cbet_device.h"
+#include "cbet_relocate.h"
 
 namespace cbet {
 namespace {
@@ -174,18 +175,6 @@ __device__ __forceinline__ bool launch_ray(const TraceArgs &a, int beam, int pre
     return true;
 }
 
-// launch_ray_XZ.cu:282-292 : nearest-node update whose lower bound follows the index it mutates.
-__device__ __forceinline__ int relocate(int c, double f, int n)
-{
-    const double half = 0.5001;  // :132
-    int q = min(n - 1, c + 1);
-    while (q >= max(0, c - 1)) {
-        c = (fabs(q - f) < half) ? q : c;
-        --q;
-    }
-    return c;
-}
-
 __device__ __forceinline__ void global_add(double *p, double v)
 {
     // native global_atomic_add_f64, no CAS loop (checked in the ISA)
@@ -313,25 +302,132 @@ __device__ __forceinline__ void lds_deposit8(LdsWindow<WL> &win, bool pending, c
 }
 
 // ---------------------------------------------------------------------------------------------
-// The ray integrator.  DEPOSIT: 1 = global atomics, 2 = LDS window of edge 2^WL.
+// Dense moving window (DEPOSIT = 3): the tuned deposit scheme.
+//
+// A wave-private W^3 tile of fp64 accumulators, addressed toroidally (haloed node index mod W per
+// axis) and covering the box [o, o+W) per axis, where the wave-uniform origin o follows the
+// bundle: each step the cell of a proxy ray (the patch's middle lane while it is alive) is kept
+// inside the box's central band.  Moving the origin by one cell along an axis retires one W x W
+// slab -- for W = 8 exactly one accumulator per lane: read it, add it to HBM with one atomic if
+// non-zero, zero it.  No tags, no compare-and-swap: a lane whose eight target nodes lie in the
+// box issues eight unconditional ds_add_f64; a lane that strays outside (a stretched bundle)
+// deposits straight to HBM for that step.  Everything is lock-step within one wave (one wave per
+// workgroup), so the origin, the shifts and the slab loops are scalar.
 // ---------------------------------------------------------------------------------------------
-template <int DEPOSIT, int WL>
+template <int WL, int RL>
+struct MovingWindow {
+    static constexpr int W = 1 << WL;
+    static constexpr int R = 1 << RL;     // privatised copies of the tile, selected by lane & (R-1)
+    static constexpr int S = W - 2;       // largest valid offset of a lane's low corner
+    // Padded layout (in doubles).  ds_add_f64 costs the CU ~8 cycles when the lanes' addresses fall on
+    // different bank pairs, +2 per lane sharing a bank, +3 per lane sharing an address (measured,
+    // scripts/ubench/lds_atomic.hip).  A bundle's footprint is a few nodes wide per axis, so rows are
+    // padded to W+1 and planes to W*(W+1)+4: neighbours in y land 9 bank pairs apart, neighbours in x
+    // 12 apart (of 16), and the copies of one node 8 apart.
+    static constexpr int YS = W + 1;
+    static constexpr int XS = W * YS + 4;
+    static constexpr int CS = W * XS + 8;          // copy stride
+    static constexpr int NDOUBLES = R * CS;
+    double *val;                          // NDOUBLES accumulators
+    int ox, oy, oz;
+
+    static __device__ __forceinline__ int addr(int rx, int ry, int rz) { return rx * XS + ry * YS + rz; }
+
+    __device__ __forceinline__ void init(int lane, int hx, int hy, int hz)
+    {
+        for (int s = lane; s < NDOUBLES; s += kWave) val[s] = 0.0;
+        ox = hx - W / 2;
+        oy = hy - W / 2;
+        oz = hz - W / 2;
+    }
+    // absolute coordinate in [o, o+W) whose residue mod W is r
+    static __device__ __forceinline__ int absolute(int o, int r) { return o + ((r - o) & (W - 1)); }
+
+    // Retire the slab `coord` (absolute, inside the box) of axis AX: flush non-zero sums, zero them.
+    template <int AX>
+    __device__ __forceinline__ void retire(int coord, int lane, double *edep, int sXh, int sYh, int &n_at)
+    {
+        const int fixed = coord & (W - 1);
+#pragma unroll
+        for (int e = lane; e < W * W; e += kWave) {
+            const int r0 = e >> WL, r1 = e & (W - 1);
+            int i, j, k, slot;
+            if (AX == 0) { i = coord; j = absolute(oy, r0); k = absolute(oz, r1); slot = addr(fixed, r0, r1); }
+            else if (AX == 1) { i = absolute(ox, r0); j = coord; k = absolute(oz, r1); slot = addr(r0, fixed, r1); }
+            else { i = absolute(ox, r0); j = absolute(oy, r1); k = coord; slot = addr(r0, r1, fixed); }
+            double v = val[slot];
+#pragma unroll
+            for (int c = 1; c < R; ++c) v += val[c * CS + slot];
+            if (v != 0.0) {  // only nodes that received deposits are non-zero, hence valid
+                global_add(&edep[(long)i * sXh + (long)j * sYh + k], v);
+#pragma unroll
+                for (int c = 0; c < R; ++c) val[c * CS + slot] = 0.0;
+                ++n_at;
+            }
+        }
+    }
+    static __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
+    template <int AX>
+    __device__ __forceinline__ void follow_axis(int &o, bool alive, int lo_corner, int lane, double *edep,
+                                                int sXh, int sYh, int &n_at)
+    {
+        // dead lanes get a neutral offset (mid-box), so no ballot needs the alive mask
+        const int rel = alive ? lo_corner - o : W / 2 - 1;
+        // one ballot decides whether anything can happen: a lane on an edge cell or outside
+        if (!any_lane((unsigned)(rel - 1) >= (unsigned)(S - 1))) return;
+        const bool below = any_lane(rel < 0), at_lo = any_lane(rel <= 0), near_lo = any_lane(rel <= 1);
+        const bool above = any_lane(rel > S), at_hi = any_lane(rel >= S), near_hi = any_lane(rel >= S - 1);
+        const bool want_down = below || (at_lo && !near_hi);
+        const bool want_up = above || (at_hi && !near_lo);
+        if (want_down && !at_hi) {
+            retire<AX>(o + W - 1, lane, edep, sXh, sYh, n_at);
+            o -= 1;
+        } else if (want_up && !at_lo) {
+            retire<AX>(o, lane, edep, sXh, sYh, n_at);
+            o += 1;
+        }
+    }
+    __device__ __forceinline__ void flush_all(int lane, double *edep, int sXh, int sYh, int &n_at)
+    {
+        for (int t = 0; t < W; ++t) retire<0>(ox + t, lane, edep, sXh, sYh, n_at);
+    }
+    __device__ __forceinline__ void add(int slot, double w)
+    {
+        __hip_atomic_fetch_add(&val[slot], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+};
+
+// 8-byte gather from a node table by 32-bit element index: uniform base + zero-extended 32-bit
+// byte offset, which the backend turns into the saddr+voffset form of global_load_dwordx2 (no
+// 64-bit address arithmetic per lane).  Valid while 8*nodes < 2^32 (checked on the host).
+template <bool IDX64>
+__device__ __forceinline__ double node_load(const double *base, unsigned idx)
+{
+    if (IDX64) return base[idx];
+    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + (idx * 8u));
+}
+
+// ---------------------------------------------------------------------------------------------
+// The ray integrator.
+//   DEPOSIT 1: 8 global atomics per step   2: tagged LDS window   3: dense moving LDS window
+//   WL       : log2 of the LDS window edge (DEPOSIT 2, 3)
+//   RL       : log2 of the number of privatised window copies (DEPOSIT 3)
+//   IDX64    : node tables of >= 2^32 bytes (n > 812)
+// ---------------------------------------------------------------------------------------------
+template <int DEPOSIT, int WL, int RL, bool IDX64>
 __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
 {
-    constexpr int NSLOT = (DEPOSIT == 2) ? (1 << (3 * WL)) : 1;
+    constexpr int NSLOT = (DEPOSIT == 3) ? MovingWindow<WL, RL>::NDOUBLES : (DEPOSIT == 2 ? (1 << (3 * WL)) : 1);
+    constexpr int NTAG = (DEPOSIT == 2) ? NSLOT : 1;
+    constexpr int W = 1 << WL;
     __shared__ double s_val[NSLOT];
-    __shared__ unsigned s_tag[NSLOT];
+    __shared__ unsigned s_tag[NTAG];
     const int lane = threadIdx.x;
-
-    LdsWindow<WL> win{s_val, s_tag};
-    if (DEPOSIT == 2) {
-        win.clear(lane);
-        __syncthreads();
-    }
 
     // which bundle: interleaved sharding over (beam, bundle) pairs
     const long g = a.shard_index + (long)a.shard_count * blockIdx.x;
-    if (g >= a.total_bundles) return;  // wave-uniform; nothing deposited yet
+    if (g >= a.total_bundles) return;  // wave-uniform
     const int beam = a.beam_lo + (int)(g / a.bundles_per_beam);
     const int li = (int)(g % a.bundles_per_beam) * kWave + lane;
 
@@ -342,28 +438,47 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
     const int launched = alive ? 1 : 0;
 
     const int nx = a.nx, ny = a.ny, nz = a.nz;
-    const long sYn = nz, sXn = (long)ny * nz;                 // node-table strides
-    const int sYh = nz + 2, sXh = (ny + 2) * (nz + 2);        // haloed edep strides (:5-7)
+    const int sY = nz, sX = ny * nz;                      // node-table strides (elements)
+    const int sYh = nz + 2, sXh = (ny + 2) * (nz + 2);    // haloed edep strides (:5-7)
+    unsigned cell = alive ? (unsigned)((s.ci * ny + s.cj) * nz + s.ck) : 0u;
     int nsteps = 0, n_atomics = 0, n_evict = 0;
 
+    LdsWindow<WL> tagged{s_val, s_tag};
+    MovingWindow<WL, RL> win{s_val, 0, 0, 0};
+    if (DEPOSIT == 2) {
+        tagged.clear(lane);
+        __syncthreads();
+    }
+    if (DEPOSIT == 3) {
+        const unsigned long long m = __ballot(alive);
+        if (m == 0) return;  // whole bundle culled (cannot happen for a listed patch; cheap guard)
+        const int src = ((m >> 27) & 1ull) ? 27 : (__ffsll((long long)m) - 1);
+        win.init(lane, __builtin_amdgcn_readlane(s.ci, src) + 1, __builtin_amdgcn_readlane(s.cj, src) + 1,
+                 __builtin_amdgcn_readlane(s.ck, src) + 1);
+        __syncthreads();
+    }
+
     for (int tt = 0; tt < a.nt; ++tt) {                        // :207
-        if (!__any(alive)) break;
+        const unsigned long long live_mask = __ballot(alive);
+        if (live_mask == 0) break;
         unsigned slot[8], node[8];
         double wgt[8];
+        int hi = 0, hj = 0, hk = 0, sx = 1, sy = 1, sz = 1;
         if (alive) {
-            // :212-238 neighbours, one-sided at the faces
-            int im = s.ci - 1, ip = s.ci + 1, jm = s.cj - 1, jp = s.cj + 1, km = s.ck - 1, kp = s.ck + 1;
-            if (s.ci == 0) { ip = 2; im = 0; } else if (s.ci == nx - 1) { ip = nx - 1; im = nx - 3; }
-            if (s.cj == 0) { jp = 2; jm = 0; } else if (s.cj == ny - 1) { jp = ny - 1; jm = ny - 3; }
-            if (s.ck == 0) { kp = 2; km = 0; } else if (s.ck == nz - 1) { kp = nz - 1; km = nz - 3; }
+            // :212-238 neighbours of the current node, one-sided at the faces, as table offsets
+            const int oxm = (s.ci == 0) ? 0 : ((s.ci == nx - 1) ? -2 * sX : -sX);
+            const int oxp = (s.ci == 0) ? 2 * sX : ((s.ci == nx - 1) ? 0 : sX);
+            const int oym = (s.cj == 0) ? 0 : ((s.cj == ny - 1) ? -2 * sY : -sY);
+            const int oyp = (s.cj == 0) ? 2 * sY : ((s.cj == ny - 1) ? 0 : sY);
+            const int ozm = (s.ck == 0) ? 0 : ((s.ck == nz - 1) ? -2 : -1);
+            const int ozp = (s.ck == 0) ? 2 : ((s.ck == nz - 1) ? 0 : 1);
             // :254-265 six gathers from the node table
-            const long row = (long)s.ci * sXn + (long)s.cj * sYn;
-            const double ne_xp = a.ne3d[(long)ip * sXn + (long)s.cj * sYn + s.ck];
-            const double ne_xm = a.ne3d[(long)im * sXn + (long)s.cj * sYn + s.ck];
-            const double ne_yp = a.ne3d[(long)s.ci * sXn + (long)jp * sYn + s.ck];
-            const double ne_ym = a.ne3d[(long)s.ci * sXn + (long)jm * sYn + s.ck];
-            const double ne_zp = a.ne3d[row + kp];
-            const double ne_zm = a.ne3d[row + km];
+            const double ne_xp = node_load<IDX64>(a.ne3d, cell + oxp);
+            const double ne_xm = node_load<IDX64>(a.ne3d, cell + oxm);
+            const double ne_yp = node_load<IDX64>(a.ne3d, cell + oyp);
+            const double ne_ym = node_load<IDX64>(a.ne3d, cell + oym);
+            const double ne_zp = node_load<IDX64>(a.ne3d, cell + ozp);
+            const double ne_zm = node_load<IDX64>(a.ne3d, cell + ozm);
             // :268-273 kick then drift
             s.vx -= a.xconst * (ne_xp - ne_xm);
             s.vy -= a.yconst * (ne_yp - ne_ym);
@@ -371,17 +486,24 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
             s.px += s.vx * a.dt;
             s.py += s.vy * a.dt;
             s.pz += s.vz * a.dt;
-            // :276-292
+            // :276-292 position in cell units, nearest-node update
             const double fx = (s.px - a.xmin) * a.inv_dx;
             const double fy = (s.py - a.ymin) * a.inv_dy;
             const double fz = (s.pz - a.zmin) * a.inv_dz;
-            s.ci = relocate(s.ci, fx, nx);
-            s.cj = relocate(s.cj, fy, ny);
-            s.ck = relocate(s.ck, fz, nz);
+            if (DEPOSIT == 3) {
+                s.ci = relocate_closed(s.ci, fx, nx);
+                s.cj = relocate_closed(s.cj, fy, ny);
+                s.ck = relocate_closed(s.ck, fz, nz);
+            } else {
+                s.ci = relocate_loop(s.ci, fx, nx);
+                s.cj = relocate_loop(s.cj, fy, ny);
+                s.ck = relocate_loop(s.ck, fz, nz);
+            }
+            cell = (unsigned)(__mul24(__mul24(s.ci, ny) + s.cj, nz) + s.ck);
             // :296-311 absorption at the new node
             double inc;
             if (a.absorption == 1) {
-                inc = a.kap3d[(long)s.ci * sXn + (long)s.cj * sYn + s.ck] * s.uray;
+                inc = node_load<IDX64>(a.kap3d, cell) * s.uray;
                 s.uray -= inc;
             } else {
                 inc = s.uray;
@@ -397,35 +519,75 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
             const double a6 = (1.0 - dl) * dn * dm;
             const double a7 = dl * dn * (1.0 - dm);
             const double a8 = dl * dn * dm;
-            const int sx = (ox < 0) ? -1 : 1, sy = (oy < 0) ? -1 : 1, sz = (oz < 0) ? -1 : 1;
+            sx = (ox < 0) ? -1 : 1;
+            sy = (oy < 0) ? -1 : 1;
+            sz = (oz < 0) ? -1 : 1;
             // :341-348 targets, reference order
-            const int hi = s.ci + 1, hj = s.cj + 1, hk = s.ck + 1;
-            const int base = hi * sXh + hj * sYh + hk;
+            hi = s.ci + 1;
+            hj = s.cj + 1;
+            hk = s.ck + 1;
+            const int base = __mul24(hi, sXh) + __mul24(hj, sYh) + hk;
+            const int dX = sx * sXh, dY = sy * sYh;
             wgt[0] = a1 * inc; node[0] = base;
-            wgt[1] = a2 * inc; node[1] = base + sx * sXh;
+            wgt[1] = a2 * inc; node[1] = base + dX;
             wgt[2] = a3 * inc; node[2] = base + sz;
-            wgt[3] = a4 * inc; node[3] = base + sx * sXh + sz;
-            wgt[4] = a5 * inc; node[4] = base + sy * sYh;
-            wgt[5] = a6 * inc; node[5] = base + sx * sXh + sy * sYh;
-            wgt[6] = a7 * inc; node[6] = base + sy * sYh + sz;
-            wgt[7] = a8 * inc; node[7] = base + sx * sXh + sy * sYh + sz;
-            if (DEPOSIT == 2) {
-                slot[0] = win.slot(hi, hj, hk);
-                slot[1] = win.slot(hi + sx, hj, hk);
-                slot[2] = win.slot(hi, hj, hk + sz);
-                slot[3] = win.slot(hi + sx, hj, hk + sz);
-                slot[4] = win.slot(hi, hj + sy, hk);
-                slot[5] = win.slot(hi + sx, hj + sy, hk);
-                slot[6] = win.slot(hi, hj + sy, hk + sz);
-                slot[7] = win.slot(hi + sx, hj + sy, hk + sz);
-            } else {
+            wgt[3] = a4 * inc; node[3] = base + dX + sz;
+            wgt[4] = a5 * inc; node[4] = base + dY;
+            wgt[5] = a6 * inc; node[5] = base + dX + dY;
+            wgt[6] = a7 * inc; node[6] = base + dY + sz;
+            wgt[7] = a8 * inc; node[7] = base + dX + dY + sz;
+            if (DEPOSIT == 1) {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) global_add(&a.edep[node[c]], wgt[c]);
                 n_atomics += 8;
             }
+            if (DEPOSIT == 2) {
+                slot[0] = tagged.slot(hi, hj, hk);
+                slot[1] = tagged.slot(hi + sx, hj, hk);
+                slot[2] = tagged.slot(hi, hj, hk + sz);
+                slot[3] = tagged.slot(hi + sx, hj, hk + sz);
+                slot[4] = tagged.slot(hi, hj + sy, hk);
+                slot[5] = tagged.slot(hi + sx, hj + sy, hk);
+                slot[6] = tagged.slot(hi, hj + sy, hk + sz);
+                slot[7] = tagged.slot(hi + sx, hj + sy, hk + sz);
+            }
             ++nsteps;
         }
-        if (DEPOSIT == 2) lds_deposit8<WL>(win, alive, slot, node, wgt, a.edep, n_evict);
+        if (DEPOSIT == 2) lds_deposit8<WL>(tagged, alive, slot, node, wgt, a.edep, n_evict);
+        if (DEPOSIT == 3) {
+            // the lane's 8 targets span {h, h+s} per axis; its low corner is h + (s>>1)  (s>>1: -1 or 0)
+            const int ax = hi + (sx >> 1), ay = hj + (sy >> 1), az = hk + (sz >> 1);
+            win.template follow_axis<0>(win.ox, alive, ax, lane, a.edep, sXh, sYh, n_atomics);
+            win.template follow_axis<1>(win.oy, alive, ay, lane, a.edep, sXh, sYh, n_atomics);
+            win.template follow_axis<2>(win.oz, alive, az, lane, a.edep, sXh, sYh, n_atomics);
+            __builtin_amdgcn_wave_barrier();
+            if (alive) {
+                const bool inbox = (unsigned)(ax - win.ox) <= (unsigned)(W - 2) &&
+                                   (unsigned)(ay - win.oy) <= (unsigned)(W - 2) &&
+                                   (unsigned)(az - win.oz) <= (unsigned)(W - 2);
+                if (inbox) {
+                    using MW = MovingWindow<WL, RL>;
+                    const int copy = (lane & (MW::R - 1)) * MW::CS;
+                    const int x0 = (hi & (W - 1)) * MW::XS + copy, x1 = ((hi + sx) & (W - 1)) * MW::XS + copy;
+                    const int y0 = (hj & (W - 1)) * MW::YS, y1 = ((hj + sy) & (W - 1)) * MW::YS;
+                    const int z0 = hk & (W - 1), z1 = (hk + sz) & (W - 1);
+                    win.add(x0 + y0 + z0, wgt[0]);
+                    win.add(x1 + y0 + z0, wgt[1]);
+                    win.add(x0 + y0 + z1, wgt[2]);
+                    win.add(x1 + y0 + z1, wgt[3]);
+                    win.add(x0 + y1 + z0, wgt[4]);
+                    win.add(x1 + y1 + z0, wgt[5]);
+                    win.add(x0 + y1 + z1, wgt[6]);
+                    win.add(x1 + y1 + z1, wgt[7]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) global_add(&a.edep[node[c]], wgt[c]);
+                    n_atomics += 8;
+                    ++n_evict;  // counted as "ray-steps that missed the window"
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
         // :351-356
         if (alive && (s.uray <= s.ustop || s.px < a.xlo || s.px > a.xhi || s.py < a.ylo ||
                       s.py > a.yhi || s.pz < a.zlo || s.pz > a.zhi))
@@ -434,7 +596,11 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
 
     if (DEPOSIT == 2) {
         __syncthreads();
-        n_atomics += win.flush(lane, a.edep) + n_evict;
+        n_atomics += tagged.flush(lane, a.edep) + n_evict;
+    }
+    if (DEPOSIT == 3) {
+        __syncthreads();
+        win.flush_all(lane, a.edep, sXh, sYh, n_atomics);
     }
     // counters: one atomic per wave and counter
     const int tot_steps = wave_sum(nsteps), tot_rays = wave_sum(launched), tot_at = wave_sum(n_atomics),
@@ -459,18 +625,34 @@ hipError_t launch_tabulate(const TabulateArgs &a, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t launch_trace(const TraceArgs &a, int variant, int window_log2, hipStream_t stream)
+template <bool IDX64>
+static void dispatch_trace(const TraceArgs &a, int variant, int wl, int rl, dim3 grid, hipStream_t stream)
+{
+    const dim3 block(kWave);
+    if (variant == CBET_KERNEL_GLOBAL_ATOMICS) {
+        hipLaunchKernelGGL((k_trace<1, 1, 0, IDX64>), grid, block, 0, stream, a);
+    } else if (variant == CBET_KERNEL_LDS_COMBINE) {
+        if (wl == 4) hipLaunchKernelGGL((k_trace<2, 4, 0, IDX64>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((k_trace<2, 3, 0, IDX64>), grid, block, 0, stream, a);
+    } else if (wl == 4) {
+        hipLaunchKernelGGL((k_trace<3, 4, 0, IDX64>), grid, block, 0, stream, a);
+    } else if (rl == 2) {
+        hipLaunchKernelGGL((k_trace<3, 3, 2, IDX64>), grid, block, 0, stream, a);
+    } else if (rl == 1) {
+        hipLaunchKernelGGL((k_trace<3, 3, 1, IDX64>), grid, block, 0, stream, a);
+    } else {
+        hipLaunchKernelGGL((k_trace<3, 3, 0, IDX64>), grid, block, 0, stream, a);
+    }
+}
+
+hipError_t launch_trace(const TraceArgs &a, int variant, int window_log2, int copies_log2, hipStream_t stream)
 {
     const long waves = (a.total_bundles - a.shard_index + a.shard_count - 1) / a.shard_count;
     if (waves <= 0) return hipSuccess;
-    const dim3 grid((unsigned)waves), block(kWave);
-    if (variant == CBET_KERNEL_GLOBAL_ATOMICS) {
-        hipLaunchKernelGGL((k_trace<1, 1>), grid, block, 0, stream, a);
-    } else if (window_log2 == 4) {
-        hipLaunchKernelGGL((k_trace<2, 4>), grid, block, 0, stream, a);
-    } else {
-        hipLaunchKernelGGL((k_trace<2, 3>), grid, block, 0, stream, a);
-    }
+    const dim3 grid((unsigned)waves);
+    const bool idx64 = (unsigned long long)a.nx * a.ny * a.nz * 8ull >= (1ull << 32);
+    if (idx64) dispatch_trace<true>(a, variant, window_log2, copies_log2, grid, stream);
+    else dispatch_trace<false>(a, variant, window_log2, copies_log2, grid, stream);
     return hipGetLastError();
 }
 

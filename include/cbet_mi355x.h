@@ -36,7 +36,8 @@ extern "C" {
 /* Kernel formulations selectable at run time (cbet_params.kernel_variant). */
 #define CBET_KERNEL_DEFAULT 0        /* the library's best parity-exact kernel */
 #define CBET_KERNEL_GLOBAL_ATOMICS 1 /* one ray per lane, 8 global fp64 atomics per step */
-#define CBET_KERNEL_LDS_COMBINE 2    /* wave-private LDS write-combining of the deposits */
+#define CBET_KERNEL_LDS_COMBINE 2    /* wave-private tagged LDS write-combining of the deposits */
+#define CBET_KERNEL_LDS_WINDOW 3     /* wave-private dense LDS window that follows the ray bundle */
 
 /*
  * Run-time counterpart of def.cuh's compile-time configuration (def.cuh:33-131).  Fill with
@@ -62,8 +63,9 @@ typedef struct cbet_params {
                                  /* bundle g is traced iff g % shard_count == shard_index      */
                                  /* (shard_count<=1: everything)                               */
     int kernel_variant;          /* CBET_KERNEL_*                                              */
-    int lds_window_log2;         /* LDS_COMBINE: log2 of the cubic window edge (3 or 4; 0=auto)*/
-    int reserved[6];
+    int lds_window_log2;         /* LDS variants: log2 of the cubic window edge (3 or 4; 0=auto)*/
+    int lds_copies_log2;         /* LDS_WINDOW: log2 of privatised tile copies (0..2; -1 = auto)*/
+    int reserved[5];
 } cbet_params;
 
 /* Quantities the reference derives in def.cuh / main.cu:156-161, evaluated in the same order. */
@@ -88,7 +90,8 @@ typedef struct cbet_counters {
     unsigned long long ray_steps;        /* integrator iterations that reached the deposition  */
     unsigned long long rays_traced;      /* live rays launched                                 */
     unsigned long long global_atomics;   /* fp64 atomics that went to HBM                      */
-    unsigned long long lds_evictions;    /* LDS_COMBINE: slots written back before the end     */
+    unsigned long long lds_evictions;    /* LDS_COMBINE: slots written back before the end;    */
+                                         /* LDS_WINDOW: ray-steps that fell outside the window */
     unsigned long long reserved[4];
 } cbet_counters;
 
@@ -202,6 +205,20 @@ int cbet_trace_nodes(int b, unsigned nindices, const double *ne3d, const double 
 int cbet_ray_tracing(const double *te_profile, const double *r_profile, const double *ne_profile,
                      double *edep, const cbet_params *p, const double *beam_norm, const int *gpus,
                      int ngpu, double *timers, cbet_counters *counters);
+
+/* ---- output stage ------------------------------------------------------ */
+/*
+ * print(std::cout, edep) under -D PRINT (main.cu:6-22, 353-355): the nested "[a,b,...]\n" text
+ * at operator<<'s default 6 significant digits -- the format of the reference's golden file
+ * truth_100 (Makefile:14-17).  edep: HOST array [d0][d1][d2].  path NULL or "-" = stdout.
+ * Returns the number of bytes written, or a negative CBET_E* code.
+ */
+long long cbet_write_text(const double *edep, int d0, int d1, int d2, const char *path);
+/*
+ * The 27-point node average of main.cu:334-349 (commented out in the reference):
+ * edepavg[nx][ny][nz] from the haloed HOST array edep[nx+2][ny+2][nz+2], same summation order.
+ */
+int cbet_edep_average(const double *edep, double *edepavg, int nx, int ny, int nz);
 
 #ifdef __cplusplus
 }

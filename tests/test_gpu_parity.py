@@ -17,7 +17,7 @@ from conftest import GOLDEN, NCPU, parity_err
 pytestmark = pytest.mark.gpu
 
 PARITY_TOL = 1e-9          # asserted;  BASELINE.json's bound is 1e-4
-VARIANTS = [1, 2]          # CBET_KERNEL_GLOBAL_ATOMICS, CBET_KERNEL_LDS_COMBINE
+VARIANTS = [1, 2, 3]     # GLOBAL_ATOMICS, LDS_COMBINE (tagged), LDS_WINDOW (default)
 
 
 @pytest.fixture(scope="module")
