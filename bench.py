@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="cbet_params.kernel_variant (0 = default)")
     ap.add_argument("--window", type=int, default=0, help="cbet_params.lds_window_log2 (0 = default)")
     ap.add_argument("--copies", type=int, default=-1, help="cbet_params.lds_copies_log2 (-1 = default)")
+    ap.add_argument("--pre", type=int, default=-1, help="cbet_params.lds_prereduce (-1 = default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -68,7 +69,7 @@ def main():
     r, ne, te = api.load_s83177()
     bn = api.omega60_beam_norm()
     p = api.default_params(n, kernel_variant=args.variant, lds_window_log2=args.window,
-                           lds_copies_log2=args.copies)
+                           lds_copies_log2=args.copies, lds_prereduce=args.pre)
     tr = RayTracer(p, r, ne, te, beam_norm=bn)
     edep = tr.new_grid()
     si, sc = shard_of_rank(rank, world)
@@ -108,7 +109,9 @@ def main():
 
     cnt = tr.counters(reset=True)
     tot = torch.tensor([float(cnt.ray_steps), float(cnt.global_atomics), elapsed,
-                        sum(a.elapsed_time(b) for a, b in ev) * 1e-3],
+                        sum(a.elapsed_time(b) for a, b in ev) * 1e-3, float(cnt.lds_evictions),
+                        float(cnt.wave_steps), float(cnt.wave_steps_miss), float(cnt.wave_steps_wide),
+                        float(cnt.slabs_retired)],
                        dtype=torch.float64, device="cuda")
     tmax = tot.clone()
     if world > 1:
@@ -137,7 +140,12 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
                          "kernel": "k_trace", "kernel_ms": 1e3 * kernel_s_rank,
                          "bytes_per_ray_step": BYTES_PER_RAY_STEP,
-                         "global_atomics_per_ray_step": tot[1].item() / max(1.0, steps_total)},
+                         "global_atomics_per_ray_step": tot[1].item() / max(1.0, steps_total),
+                         "lane_utilisation": steps_total / max(1.0, 64.0 * tot[5].item()),
+                         "window_miss_ray_step_frac": tot[4].item() / max(1.0, steps_total),
+                         "window_miss_wave_step_frac": tot[6].item() / max(1.0, tot[5].item()),
+                         "window_too_narrow_wave_step_frac": tot[7].item() / max(1.0, tot[5].item()),
+                         "slabs_retired_per_wave_step": tot[8].item() / max(1.0, tot[5].item())},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, r, ne, te, bn)

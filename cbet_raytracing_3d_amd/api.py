@@ -15,7 +15,8 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libcbet_mi355x.so")
+# CBET_LIB_PATH: point at an alternative build of the same library (profiling experiments only)
+LIB_PATH = os.environ.get("CBET_LIB_PATH") or os.path.join(_PKG, "lib", "libcbet_mi355x.so")
 DATA_DIR = os.path.join(_PKG, "data")
 
 OK, EINVAL, EHIP, ENOMEM, ENODEVICE, ECOMM = 0, -1, -2, -3, -4, -5
@@ -44,7 +45,7 @@ class Params(C.Structure):
         ("beam_lo", C.c_int), ("beam_hi", C.c_int),
         ("shard_index", C.c_int), ("shard_count", C.c_int),
         ("kernel_variant", C.c_int), ("lds_window_log2", C.c_int), ("lds_copies_log2", C.c_int),
-        ("reserved", C.c_int * 5),
+        ("lds_prereduce", C.c_int), ("reserved", C.c_int * 4),
     ]
 
     def copy(self, **overrides):
@@ -72,7 +73,8 @@ class Counters(C.Structure):
     _fields_ = [
         ("ray_steps", C.c_ulonglong), ("rays_traced", C.c_ulonglong),
         ("global_atomics", C.c_ulonglong), ("lds_evictions", C.c_ulonglong),
-        ("reserved", C.c_ulonglong * 4),
+        ("wave_steps", C.c_ulonglong), ("wave_steps_miss", C.c_ulonglong),
+        ("wave_steps_wide", C.c_ulonglong), ("slabs_retired", C.c_ulonglong),
     ]
 
 

@@ -212,6 +212,7 @@ int cbet_params_default(cbet_params *p, int n)
     p->shard_count = 1;
     p->kernel_variant = CBET_KERNEL_DEFAULT;
     p->lds_copies_log2 = -1;
+    p->lds_prereduce = -1;
     return CBET_OK;
 }
 
@@ -408,6 +409,10 @@ int cbet_context_counters(cbet_context *ctx, void *stream, cbet_counters *out, i
     out->rays_traced = h[kCntRays];
     out->global_atomics = h[kCntGlobalAtomics];
     out->lds_evictions = h[kCntEvictions];
+    out->wave_steps = h[kCntWaveSteps];
+    out->wave_steps_miss = h[kCntWaveStepsMiss];
+    out->wave_steps_wide = h[kCntWaveStepsWide];
+    out->slabs_retired = h[kCntSlabsRetired];
     return CBET_OK;
 }
 
@@ -485,6 +490,8 @@ int cbet_trace_nodes(int b, unsigned nindices, const double *ne3d, const double 
     if (wl != 3 && wl != 4) return fail(CBET_EINVAL, "lds_window_log2 must be 3 or 4");
     int rl = p->lds_copies_log2 < 0 ? 1 : p->lds_copies_log2;  // auto: 2 copies (measured best)
     if (rl > 2) return fail(CBET_EINVAL, "lds_copies_log2 must be -1 (auto) or 0..2");
+    int pre = p->lds_prereduce < 0 ? 0 : p->lds_prereduce;
+    if (pre > 2) return fail(CBET_EINVAL, "lds_prereduce must be -1 (auto) or 0..2");
 
     const cbet_derived &d = ctx->d;
     TraceArgs a{};
@@ -516,7 +523,7 @@ int cbet_trace_nodes(int b, unsigned nindices, const double *ne3d, const double 
 
     DeviceGuard guard;
     CBET_HIP(hipSetDevice(ctx->gpu));
-    CBET_HIP(launch_trace(a, variant, wl, rl, (hipStream_t)stream));
+    CBET_HIP(launch_trace(a, variant, wl, rl, pre, (hipStream_t)stream));
     return CBET_OK;
 }
 

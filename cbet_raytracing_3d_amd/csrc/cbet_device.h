@@ -25,7 +25,8 @@ constexpr unsigned kEmptyTag = 0xFFFFFFFFu;
 constexpr int kWave = 64;
 
 // Device counter slots (unsigned long long each); mirrors cbet_counters.
-enum CounterSlot { kCntSteps = 0, kCntRays = 1, kCntGlobalAtomics = 2, kCntEvictions = 3, kCntSlots = 8 };
+enum CounterSlot { kCntSteps = 0, kCntRays = 1, kCntGlobalAtomics = 2, kCntEvictions = 3, kCntWaveSteps = 4,
+                   kCntWaveStepsMiss = 5, kCntWaveStepsWide = 6, kCntSlabsRetired = 7, kCntSlots = 8 };
 
 // Everything the tabulation kernel needs.
 struct TabulateArgs {
@@ -67,7 +68,8 @@ struct TraceArgs {
 };
 
 hipError_t launch_tabulate(const TabulateArgs &a, hipStream_t stream);
-hipError_t launch_trace(const TraceArgs &a, int variant, int window_log2, int copies_log2, hipStream_t stream);
+hipError_t launch_trace(const TraceArgs &a, int variant, int window_log2, int copies_log2, int prereduce,
+                        hipStream_t stream);
 
 }  // namespace cbet
 #endif

@@ -198,6 +198,10 @@ extern "C" int cbet_ray_tracing(const double *te_profile, const double *r_profil
             counters->rays_traced += j.counters.rays_traced;
             counters->global_atomics += j.counters.global_atomics;
             counters->lds_evictions += j.counters.lds_evictions;
+            counters->wave_steps += j.counters.wave_steps;
+            counters->wave_steps_miss += j.counters.wave_steps_miss;
+            counters->wave_steps_wide += j.counters.wave_steps_wide;
+            counters->slabs_retired += j.counters.slabs_retired;
         }
     }
     for (auto &j : jobs) release(j);

@@ -359,7 +359,9 @@ struct MovingWindow {
 #pragma unroll
             for (int c = 1; c < R; ++c) v += val[c * CS + slot];
             if (v != 0.0) {  // only nodes that received deposits are non-zero, hence valid
+#ifndef CBET_EXPERIMENT_DROP_FLUSH_ATOMICS  // timing-only experiment builds (scripts/experiment_*.sh); never shipped
                 global_add(&edep[(long)i * sXh + (long)j * sYh + k], v);
+#endif
 #pragma unroll
                 for (int c = 0; c < R; ++c) val[c * CS + slot] = 0.0;
                 ++n_at;
@@ -370,7 +372,7 @@ struct MovingWindow {
 
     template <int AX>
     __device__ __forceinline__ void follow_axis(int &o, bool alive, int lo_corner, int lane, double *edep,
-                                                int sXh, int sYh, int &n_at)
+                                                int sXh, int sYh, int &n_at, int &n_wide, int &n_slabs)
     {
         // dead lanes get a neutral offset (mid-box), so no ballot needs the alive mask
         const int rel = alive ? lo_corner - o : W / 2 - 1;
@@ -380,12 +382,15 @@ struct MovingWindow {
         const bool above = any_lane(rel > S), at_hi = any_lane(rel >= S), near_hi = any_lane(rel >= S - 1);
         const bool want_down = below || (at_lo && !near_hi);
         const bool want_up = above || (at_hi && !near_lo);
+        if (below && above) ++n_wide;  // wave-uniform: the bundle does not fit the box on this axis
         if (want_down && !at_hi) {
             retire<AX>(o + W - 1, lane, edep, sXh, sYh, n_at);
             o -= 1;
+            ++n_slabs;
         } else if (want_up && !at_lo) {
             retire<AX>(o, lane, edep, sXh, sYh, n_at);
             o += 1;
+            ++n_slabs;
         }
     }
     __device__ __forceinline__ void flush_all(int lane, double *edep, int sXh, int sYh, int &n_at)
@@ -397,6 +402,37 @@ struct MovingWindow {
         __hip_atomic_fetch_add(&val[slot], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 };
+
+// Cross-lane moves inside a quad (4 consecutive lanes = 4 rays a quarter cell apart along the
+// patch's x axis) through DPP: no LDS, one VALU op per 32-bit half.
+template <int CTRL>
+__device__ __forceinline__ int quad_i(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ double quad_d(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = quad_i<CTRL>((int)b), hi = quad_i<CTRL>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+// One level of the in-register pre-reduction: lanes l and l^M whose rays target the same 8 nodes
+// (equal key) merge -- the lower lane takes the sum, the upper lane stops depositing (its key
+// becomes a unique negative value, so it can never match again).
+template <int CTRL, int M>
+__device__ __forceinline__ void merge_level(int lane, int &key, double (&w)[8])
+{
+    const int pk = quad_i<CTRL>(key);
+    const bool same = (pk == key) && key >= 0;
+    const bool lower = (lane & M) == 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const double pw = quad_d<CTRL>(w[c]);
+        if (same && lower) w[c] += pw;
+    }
+    if (same && !lower) key = -2 - lane;
+}
 
 // 8-byte gather from a node table by 32-bit element index: uniform base + zero-extended 32-bit
 // byte offset, which the backend turns into the saddr+voffset form of global_load_dwordx2 (no
@@ -413,9 +449,10 @@ __device__ __forceinline__ double node_load(const double *base, unsigned idx)
 //   DEPOSIT 1: 8 global atomics per step   2: tagged LDS window   3: dense moving LDS window
 //   WL       : log2 of the LDS window edge (DEPOSIT 2, 3)
 //   RL       : log2 of the number of privatised window copies (DEPOSIT 3)
+//   PRE      : levels of in-register pre-reduction across neighbouring lanes (DEPOSIT 3; 0, 1, 2)
 //   IDX64    : node tables of >= 2^32 bytes (n > 812)
 // ---------------------------------------------------------------------------------------------
-template <int DEPOSIT, int WL, int RL, bool IDX64>
+template <int DEPOSIT, int WL, int RL, int PRE, bool IDX64>
 __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
 {
     constexpr int NSLOT = (DEPOSIT == 3) ? MovingWindow<WL, RL>::NDOUBLES : (DEPOSIT == 2 ? (1 << (3 * WL)) : 1);
@@ -442,6 +479,7 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
     const int sYh = nz + 2, sXh = (ny + 2) * (nz + 2);    // haloed edep strides (:5-7)
     unsigned cell = alive ? (unsigned)((s.ci * ny + s.cj) * nz + s.ck) : 0u;
     int nsteps = 0, n_atomics = 0, n_evict = 0;
+    int w_steps = 0, w_miss = 0, w_wide = 0, w_slabs = 0;  // wave-uniform diagnostics
 
     LdsWindow<WL> tagged{s_val, s_tag};
     MovingWindow<WL, RL> win{s_val, 0, 0, 0};
@@ -461,6 +499,7 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
     for (int tt = 0; tt < a.nt; ++tt) {                        // :207
         const unsigned long long live_mask = __ballot(alive);
         if (live_mask == 0) break;
+        ++w_steps;
         unsigned slot[8], node[8];
         double wgt[8];
         int hi = 0, hj = 0, hk = 0, sx = 1, sy = 1, sz = 1;
@@ -557,34 +596,41 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
         if (DEPOSIT == 3) {
             // the lane's 8 targets span {h, h+s} per axis; its low corner is h + (s>>1)  (s>>1: -1 or 0)
             const int ax = hi + (sx >> 1), ay = hj + (sy >> 1), az = hk + (sz >> 1);
-            win.template follow_axis<0>(win.ox, alive, ax, lane, a.edep, sXh, sYh, n_atomics);
-            win.template follow_axis<1>(win.oy, alive, ay, lane, a.edep, sXh, sYh, n_atomics);
-            win.template follow_axis<2>(win.oz, alive, az, lane, a.edep, sXh, sYh, n_atomics);
+            int wide = 0;
+            win.template follow_axis<0>(win.ox, alive, ax, lane, a.edep, sXh, sYh, n_atomics, wide, w_slabs);
+            win.template follow_axis<1>(win.oy, alive, ay, lane, a.edep, sXh, sYh, n_atomics, wide, w_slabs);
+            win.template follow_axis<2>(win.oz, alive, az, lane, a.edep, sXh, sYh, n_atomics, wide, w_slabs);
             __builtin_amdgcn_wave_barrier();
-            if (alive) {
-                const bool inbox = (unsigned)(ax - win.ox) <= (unsigned)(W - 2) &&
-                                   (unsigned)(ay - win.oy) <= (unsigned)(W - 2) &&
-                                   (unsigned)(az - win.oz) <= (unsigned)(W - 2);
-                if (inbox) {
-                    using MW = MovingWindow<WL, RL>;
-                    const int copy = (lane & (MW::R - 1)) * MW::CS;
-                    const int x0 = (hi & (W - 1)) * MW::XS + copy, x1 = ((hi + sx) & (W - 1)) * MW::XS + copy;
-                    const int y0 = (hj & (W - 1)) * MW::YS, y1 = ((hj + sy) & (W - 1)) * MW::YS;
-                    const int z0 = hk & (W - 1), z1 = (hk + sz) & (W - 1);
-                    win.add(x0 + y0 + z0, wgt[0]);
-                    win.add(x1 + y0 + z0, wgt[1]);
-                    win.add(x0 + y0 + z1, wgt[2]);
-                    win.add(x1 + y0 + z1, wgt[3]);
-                    win.add(x0 + y1 + z0, wgt[4]);
-                    win.add(x1 + y1 + z0, wgt[5]);
-                    win.add(x0 + y1 + z1, wgt[6]);
-                    win.add(x1 + y1 + z1, wgt[7]);
-                } else {
+            const bool inbox = alive && (unsigned)(ax - win.ox) <= (unsigned)(W - 2) &&
+                               (unsigned)(ay - win.oy) <= (unsigned)(W - 2) &&
+                               (unsigned)(az - win.oz) <= (unsigned)(W - 2);
+            if (__builtin_amdgcn_ballot_w64(alive && !inbox) != 0ull) {
+                ++w_miss;
+                w_wide += wide ? 1 : 0;
+            }
+            // key: identifies the ordered set of 8 target nodes (base node + the three signs)
+            int key = inbox ? (int)((node[0] << 3) | ((sx & 2) << 1) | (sy & 2) | ((sz & 2) >> 1)) : -2 - lane;
+            if (PRE >= 1) merge_level<0xB1, 1>(lane, key, wgt);   // quad_perm [1,0,3,2]: lane ^ 1
+            if (PRE >= 2) merge_level<0x4E, 2>(lane, key, wgt);   // quad_perm [2,3,0,1]: lane ^ 2
+            if (key >= 0) {
+                using MW = MovingWindow<WL, RL>;
+                const int copy = ((lane >> PRE) & (MW::R - 1)) * MW::CS;
+                const int x0 = (hi & (W - 1)) * MW::XS + copy, x1 = ((hi + sx) & (W - 1)) * MW::XS + copy;
+                const int y0 = (hj & (W - 1)) * MW::YS, y1 = ((hj + sy) & (W - 1)) * MW::YS;
+                const int z0 = hk & (W - 1), z1 = (hk + sz) & (W - 1);
+                win.add(x0 + y0 + z0, wgt[0]);
+                win.add(x1 + y0 + z0, wgt[1]);
+                win.add(x0 + y0 + z1, wgt[2]);
+                win.add(x1 + y0 + z1, wgt[3]);
+                win.add(x0 + y1 + z0, wgt[4]);
+                win.add(x1 + y1 + z0, wgt[5]);
+                win.add(x0 + y1 + z1, wgt[6]);
+                win.add(x1 + y1 + z1, wgt[7]);
+            } else if (alive && !inbox) {
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) global_add(&a.edep[node[c]], wgt[c]);
-                    n_atomics += 8;
-                    ++n_evict;  // counted as "ray-steps that missed the window"
-                }
+                for (int c = 0; c < 8; ++c) global_add(&a.edep[node[c]], wgt[c]);
+                n_atomics += 8;
+                ++n_evict;  // counted as "ray-steps that missed the window"
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -610,6 +656,12 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
         atomicAdd(&a.counters[kCntRays], (unsigned long long)tot_rays);
         atomicAdd(&a.counters[kCntGlobalAtomics], (unsigned long long)tot_at);
         atomicAdd(&a.counters[kCntEvictions], (unsigned long long)tot_ev);
+        atomicAdd(&a.counters[kCntWaveSteps], (unsigned long long)w_steps);
+        if (DEPOSIT == 3) {
+            atomicAdd(&a.counters[kCntWaveStepsMiss], (unsigned long long)w_miss);
+            atomicAdd(&a.counters[kCntWaveStepsWide], (unsigned long long)w_wide);
+            atomicAdd(&a.counters[kCntSlabsRetired], (unsigned long long)w_slabs);
+        }
     }
 }
 
@@ -625,34 +677,49 @@ hipError_t launch_tabulate(const TabulateArgs &a, hipStream_t stream)
     return hipGetLastError();
 }
 
+template <int RL, int PRE, bool IDX64>
+static void launch_window8(const TraceArgs &a, dim3 grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL((k_trace<3, 3, RL, PRE, IDX64>), grid, dim3(kWave), 0, stream, a);
+}
+
 template <bool IDX64>
-static void dispatch_trace(const TraceArgs &a, int variant, int wl, int rl, dim3 grid, hipStream_t stream)
+static void dispatch_trace(const TraceArgs &a, int variant, int wl, int rl, int pre, dim3 grid, hipStream_t stream)
 {
     const dim3 block(kWave);
     if (variant == CBET_KERNEL_GLOBAL_ATOMICS) {
-        hipLaunchKernelGGL((k_trace<1, 1, 0, IDX64>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((k_trace<1, 1, 0, 0, IDX64>), grid, block, 0, stream, a);
     } else if (variant == CBET_KERNEL_LDS_COMBINE) {
-        if (wl == 4) hipLaunchKernelGGL((k_trace<2, 4, 0, IDX64>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((k_trace<2, 3, 0, IDX64>), grid, block, 0, stream, a);
+        if (wl == 4) hipLaunchKernelGGL((k_trace<2, 4, 0, 0, IDX64>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((k_trace<2, 3, 0, 0, IDX64>), grid, block, 0, stream, a);
     } else if (wl == 4) {
-        hipLaunchKernelGGL((k_trace<3, 4, 0, IDX64>), grid, block, 0, stream, a);
-    } else if (rl == 2) {
-        hipLaunchKernelGGL((k_trace<3, 3, 2, IDX64>), grid, block, 0, stream, a);
-    } else if (rl == 1) {
-        hipLaunchKernelGGL((k_trace<3, 3, 1, IDX64>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((k_trace<3, 4, 0, 0, IDX64>), grid, block, 0, stream, a);
     } else {
-        hipLaunchKernelGGL((k_trace<3, 3, 0, IDX64>), grid, block, 0, stream, a);
+        switch (rl * 3 + pre) {
+        case 0: launch_window8<0, 0, IDX64>(a, grid, stream); break;
+        case 1: launch_window8<0, 1, IDX64>(a, grid, stream); break;
+        case 2: launch_window8<0, 2, IDX64>(a, grid, stream); break;
+        case 3: launch_window8<1, 0, IDX64>(a, grid, stream); break;
+        case 4: launch_window8<1, 1, IDX64>(a, grid, stream); break;
+        case 5: launch_window8<1, 2, IDX64>(a, grid, stream); break;
+        case 6: launch_window8<2, 0, IDX64>(a, grid, stream); break;
+        case 7: launch_window8<2, 1, IDX64>(a, grid, stream); break;
+        default: launch_window8<2, 2, IDX64>(a, grid, stream); break;
+        }
     }
 }
 
-hipError_t launch_trace(const TraceArgs &a, int variant, int window_log2, int copies_log2, hipStream_t stream)
+hipError_t launch_trace(const TraceArgs &a, int variant, int window_log2, int copies_log2, int prereduce,
+                        hipStream_t stream)
 {
     const long waves = (a.total_bundles - a.shard_index + a.shard_count - 1) / a.shard_count;
     if (waves <= 0) return hipSuccess;
     const dim3 grid((unsigned)waves);
     const bool idx64 = (unsigned long long)a.nx * a.ny * a.nz * 8ull >= (1ull << 32);
-    if (idx64) dispatch_trace<true>(a, variant, window_log2, copies_log2, grid, stream);
-    else dispatch_trace<false>(a, variant, window_log2, copies_log2, grid, stream);
+    // the pre-reduction key packs (flat haloed node index << 3 | signs) into 31 bits
+    if ((long)(a.nx + 2) * (a.ny + 2) * (a.nz + 2) >= (1L << 28)) prereduce = 0;
+    if (idx64) dispatch_trace<true>(a, variant, window_log2, copies_log2, prereduce, grid, stream);
+    else dispatch_trace<false>(a, variant, window_log2, copies_log2, prereduce, grid, stream);
     return hipGetLastError();
 }
 

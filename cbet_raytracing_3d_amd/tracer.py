@@ -53,7 +53,8 @@ class RayTracer:
         return torch.zeros(self.grid_shape, dtype=torch.float64, device=self.device)
 
     def launch(self, edep, shard_index=0, shard_count=1, beam_lo=0, beam_hi=None,
-               kernel_variant=None, lds_window_log2=None, lds_copies_log2=None, use_host_trig=True):
+               kernel_variant=None, lds_window_log2=None, lds_copies_log2=None, lds_prereduce=None,
+               use_host_trig=True):
         """Enqueue one launch_ray_XYZ on torch's current stream, accumulating into `edep`."""
         if edep.dtype != torch.float64 or not edep.is_contiguous() or tuple(edep.shape) != self.grid_shape:
             raise ValueError("edep must be a contiguous float64 tensor of shape %s" % (self.grid_shape,))
@@ -66,6 +67,8 @@ class RayTracer:
             p.lds_window_log2 = lds_window_log2
         if lds_copies_log2 is not None:
             p.lds_copies_log2 = lds_copies_log2
+        if lds_prereduce is not None:
+            p.lds_prereduce = lds_prereduce
         d = self.derived
         stream = torch.cuda.current_stream(self.device).cuda_stream
         api.launch_ray_XYZ(0, d.nindices, self.d_te, self.d_r, self.d_ne, edep,

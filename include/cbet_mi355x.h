@@ -65,7 +65,8 @@ typedef struct cbet_params {
     int kernel_variant;          /* CBET_KERNEL_*                                              */
     int lds_window_log2;         /* LDS variants: log2 of the cubic window edge (3 or 4; 0=auto)*/
     int lds_copies_log2;         /* LDS_WINDOW: log2 of privatised tile copies (0..2; -1 = auto)*/
-    int reserved[5];
+    int lds_prereduce;           /* LDS_WINDOW: levels of in-register lane merging (0..2; -1 = auto)*/
+    int reserved[4];
 } cbet_params;
 
 /* Quantities the reference derives in def.cuh / main.cu:156-161, evaluated in the same order. */
@@ -92,7 +93,10 @@ typedef struct cbet_counters {
     unsigned long long global_atomics;   /* fp64 atomics that went to HBM                      */
     unsigned long long lds_evictions;    /* LDS_COMBINE: slots written back before the end;    */
                                          /* LDS_WINDOW: ray-steps that fell outside the window */
-    unsigned long long reserved[4];
+    unsigned long long wave_steps;       /* integrator iterations per wavefront (64 lane slots each) */
+    unsigned long long wave_steps_miss;  /* LDS_WINDOW: wave-steps in which some lane missed the window */
+    unsigned long long wave_steps_wide;  /* LDS_WINDOW: of those, the bundle was wider than the window  */
+    unsigned long long slabs_retired;    /* LDS_WINDOW: window slabs flushed because the box moved      */
 } cbet_counters;
 
 typedef struct cbet_context cbet_context; /* per-device workspace: node tables, ray list, counters */

@@ -162,3 +162,43 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "cbet_oracle" not in text and "import oracle" not in text, f
+
+
+def test_text_writer_matches_reference_format(api, oracle, inputs, tmp_path):
+    """cbet_write_text (main.cu:6-22): byte-identical to the oracle's writer on awkward values, and
+    the truth_100 md5 when fed the oracle's 100^3 grid (the reference's `make test`, Makefile:14-17)."""
+    import hashlib
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal((3, 4, 5)) * 10.0 ** rng.integers(-8, 14, (3, 4, 5))
+    a[0, 0, 0], a[1, 2, 3], a[2, 3, 4], a[0, 1, 1] = 0.0, -0.0, 1e6, 123456.5
+    p1, p2 = str(tmp_path / "a.txt"), str(tmp_path / "b.txt")
+    n1, n2 = api.write_text(a, p1), oracle.write_text(a, p2)
+    assert n1 == n2 == os.path.getsize(p1)
+    assert open(p1, "rb").read() == open(p2, "rb").read()
+    assert open(p1).read().startswith("[[[") and open(p1).read().endswith("]\n]\n]\n")
+    bn, r, ne, te = inputs
+    e, _ = oracle.trace(oracle.default_config(100), bn, r, ne, te, nthreads=os.cpu_count())
+    p3 = str(tmp_path / "truth.txt")
+    assert api.write_text(e, p3) == 12544620
+    assert hashlib.md5(open(p3, "rb").read()).hexdigest() == "cc0909ed1c5938704c51165dc20cb829"
+
+
+def test_edep_average(api):
+    rng = np.random.default_rng(7)
+    e = rng.uniform(0, 1e12, (7, 9, 8))
+    got = api.edep_average(e)
+    assert got.shape == (5, 7, 6)
+    want = np.zeros_like(got)
+    for di in range(3):
+        for dj in range(3):
+            for dk in range(3):
+                want += e[di:di + 5, dj:dj + 7, dk:dk + 6]
+    assert np.allclose(got, want / 27, rtol=1e-14, atol=0)
+    # literal order of main.cu:338-346 for one cell: k-offset outermost, then j, then i
+    acc = None
+    for dk in range(3):
+        for dj in range(3):
+            for di in range(3):
+                v = e[2 + di, 3 + dj, 1 + dk]
+                acc = v if acc is None else acc + v
+    assert got[2, 3, 1] == acc / 27

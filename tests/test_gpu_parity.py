@@ -161,7 +161,9 @@ def test_truth_100_golden(api, oracle, inputs, torch_cuda, golden, variant, tmp_
                       ("face_z0", e[:, :, 0])):
         assert parity_err(got, planes[name]) < PARITY_TOL, name
     path = str(tmp_path / "edep.txt")
-    assert oracle.write_text(e, path) == g["text_bytes"] == 12544620
+    assert api.write_text(e, path) == g["text_bytes"] == 12544620        # the product's own writer
+    assert hashlib.md5(open(path, "rb").read()).hexdigest() == g["text_md5"] == "cc0909ed1c5938704c51165dc20cb829"
+    assert oracle.write_text(e, path) == g["text_bytes"]
     assert hashlib.md5(open(path, "rb").read()).hexdigest() == g["text_md5"]
     tr.close()
 
@@ -285,4 +287,58 @@ def test_full_size_256_properties(api, inputs, torch_cuda):
     assert parity_err(e2, e1) < 1e-10
     print("256^3: LDS-combine global atomics per ray-step = %.3f (global variant: 8)" %
           (c2.global_atomics / c2.ray_steps))
+    tr.close()
+
+
+def test_cli_driver_reproduces_truth_100():
+    """tools/cbet_gpu.cpp = main.cu's driver over the C ABI: `cbet-gpu 10 --print` must emit the
+    reference's golden text (Makefile:14-17), and without --print the four timers (main.cu:225-230)."""
+    import subprocess
+    from cbet_raytracing_3d_amd import build
+    from conftest import ROOT
+    exe = build.CLI_PATH
+    assert os.path.exists(exe), "cbet-gpu not built"
+    out = subprocess.run([exe, "10", "--n", "100", "--print"], cwd=ROOT, capture_output=True, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()
+    assert len(out.stdout) == 12544620
+    assert hashlib.md5(out.stdout).hexdigest() == "cc0909ed1c5938704c51165dc20cb829"
+    out = subprocess.run([exe, "10", "--n", "64"], cwd=ROOT, capture_output=True, timeout=300, text=True)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.splitlines()
+    assert lines[0].startswith("rt: Init ") and lines[1].startswith("Tracing ")
+    assert lines[2].startswith("Combining ") and lines[3].startswith("Total ")
+    assert "ray-steps 30712072" in lines[4]
+
+
+def test_trace_with_caller_supplied_node_tables(api, oracle, inputs, torch_cuda):
+    """the 3-D plasma entry.  Tables supplied by the caller (here: the oracle's
+    node tables, uploaded) must give the same grid as the radial-profile launch; a non-spherical
+    edit of kappa3d changes only the absorption, energy still balances."""
+    bn, r, ne, te = inputs
+    tr = make_tracer(api, inputs, 48, nbeams=6)
+    ref, c = run(tr, torch_cuda)
+    one3d, okap = oracle.node_tables(oracle.default_config(48), r, ne, te)
+    d_ne = torch_cuda.from_numpy(one3d).cuda()
+    d_kap = torch_cuda.from_numpy(okap).cuda()
+    d = tr.derived
+    stream = torch_cuda.cuda.current_stream().cuda_stream
+
+    def trace(kap):
+        e = tr.new_grid()
+        tr.counters(reset=True)
+        api.trace_nodes(0, d.nindices, d_ne, kap, e, tr.d_bbeam_norm, tr.d_beam_norm, tr.d_pow_r,
+                        tr.d_phase_r, d.xconst, d.yconst, d.zconst, tr.params.copy(beam_lo=0, beam_hi=6),
+                        tr.ctx, stream)
+        return e.cpu().numpy(), tr.counters(reset=True)
+
+    got, c2 = trace(d_kap)
+    assert c2.ray_steps == c.ray_steps and parity_err(got, ref) < 1e-11
+    half = d_kap.clone()
+    half[:24] *= 0.5                                   # weaker absorption in the x < 0 half-space
+    got2, c3 = trace(half)
+    assert c3.ray_steps > c.ray_steps                  # rays survive longer
+    # beams 0-5 enter from +x (omega_beams.h rows 0-29 have n_x >= 0): upstream half untouched,
+    # downstream half absorbs differently
+    assert parity_err(got2[30:], got[30:]) < 1e-11
+    assert abs(got2[:22].sum() / got[:22].sum() - 1) > 1e-3
     tr.close()
