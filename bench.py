@@ -24,15 +24,31 @@ HBM_PEAK = 8.0e12             # MI355X_MICROARCH.md: HBM3E spec B/s (6.29e12 mea
 
 def cpu_baseline(n, r, ne, te, bn):
     """The serial CPU ray loop (oracle/cbet_oracle.c, 1 thread) on a bounded sample of the same
-    workload: beam 0 of the n^3 sweep (~1/60 of the ray-steps)."""
+    workload: the first beams of the n^3 sweep (~1e8 ray-steps, 10-30 s)."""
     from oracle import cbet_oracle as O
     cfg = O.default_config(n)
+    nb = 3 if n >= 200 else 60
     t0 = time.perf_counter()
-    _, steps = O.trace(cfg, bn, r, ne, te, beam_lo=0, beam_hi=1, nthreads=1)
+    _, steps = O.trace(cfg, bn, r, ne, te, beam_lo=0, beam_hi=nb, nthreads=1)
     dt = time.perf_counter() - t0
     return {"value": steps / dt, "unit": "ray-steps/s", "cores": 1, "kind": "port",
-            "sample": "beam 0 of the %d^3 60-beam s83177 sweep: %d ray-steps in %.1f s, "
-                      "1 thread, gcc -O2 -ffp-contract=off" % (n, steps, dt)}
+            "sample": "beams 0-%d of the %d^3 60-beam s83177 sweep: %d ray-steps in %.1f s, "
+                      "serial ray loop, 1 thread, gcc -O2 -ffp-contract=off" % (nb - 1, n, steps, dt)}
+
+
+def measured_traffic(workload, variant):
+    """HBM bytes per k_trace launch from the committed PMC passes (profiles/*/traffic.json:
+    (FETCH_SIZE + WRITE_SIZE) * 1 KiB, collected in separate --pmc passes).  None when no profile
+    exists for this exact workload / kernel configuration."""
+    best = None
+    prof = os.path.join(ROOT, "profiles")
+    for rnd in sorted(os.listdir(prof)) if os.path.isdir(prof) else []:
+        path = os.path.join(prof, rnd, "traffic.json")
+        if os.path.exists(path):
+            for e in json.load(open(path)).get("entries", []):
+                if e.get("workload") == workload and e.get("kernel_variant") == variant:
+                    best = e
+    return best
 
 
 def main():
@@ -45,6 +61,8 @@ def main():
     ap.add_argument("--window", type=int, default=0, help="cbet_params.lds_window_log2 (0 = default)")
     ap.add_argument("--copies", type=int, default=-1, help="cbet_params.lds_copies_log2 (-1 = default)")
     ap.add_argument("--pre", type=int, default=-1, help="cbet_params.lds_prereduce (-1 = default)")
+    ap.add_argument("--flip", type=int, default=-1, help="cbet_params.lds_corner_flip (-1 = default)")
+    ap.add_argument("--twobox", type=int, default=-1, help="cbet_params.lds_two_boxes (-1 = default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -69,7 +87,8 @@ def main():
     r, ne, te = api.load_s83177()
     bn = api.omega60_beam_norm()
     p = api.default_params(n, kernel_variant=args.variant, lds_window_log2=args.window,
-                           lds_copies_log2=args.copies, lds_prereduce=args.pre)
+                           lds_copies_log2=args.copies, lds_prereduce=args.pre,
+                           lds_corner_flip=args.flip, lds_two_boxes=args.twobox)
     tr = RayTracer(p, r, ne, te, beam_norm=bn)
     edep = tr.new_grid()
     si, sc = shard_of_rank(rank, world)
@@ -124,6 +143,7 @@ def main():
 
     if rank == 0:
         steps_per_launch = steps_total / args.steps / world   # ray-steps one launch processes (avg rank)
+        traffic = measured_traffic("omega60_%dcube_s83177_absorption" % n, args.variant) if world == 1 else None
         achieved = steps_per_launch * BYTES_PER_RAY_STEP / kernel_s_rank
         out = {
             "metric": "ray-steps/sec, OMEGA 60-beam %d^3 sweep" % n,
@@ -137,7 +157,12 @@ def main():
                        "sharding": "ray bundles interleaved over %d rank(s), all-reduce of the "
                                    "(n+2)^3 fp64 grid per pass" % world},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK,
+                         "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
+                         "traffic_source": traffic["source"] if traffic else None,
+                         "note": "achieved = algorithmic bytes (128 B/ray-step) / kernel time; it can exceed the "
+                                 "HBM peak because gathers are served by L1/L2/MALL and scatters are combined "
+                                 "in LDS -- see traffic (measured HBM bytes per launch) and DESIGN.md 4.3",
                          "kernel": "k_trace", "kernel_ms": 1e3 * kernel_s_rank,
                          "bytes_per_ray_step": BYTES_PER_RAY_STEP,
                          "global_atomics_per_ray_step": tot[1].item() / max(1.0, steps_total),

@@ -45,7 +45,8 @@ class Params(C.Structure):
         ("beam_lo", C.c_int), ("beam_hi", C.c_int),
         ("shard_index", C.c_int), ("shard_count", C.c_int),
         ("kernel_variant", C.c_int), ("lds_window_log2", C.c_int), ("lds_copies_log2", C.c_int),
-        ("lds_prereduce", C.c_int), ("reserved", C.c_int * 4),
+        ("lds_prereduce", C.c_int), ("lds_corner_flip", C.c_int),
+        ("lds_two_boxes", C.c_int), ("reserved", C.c_int * 2),
     ]
 
     def copy(self, **overrides):

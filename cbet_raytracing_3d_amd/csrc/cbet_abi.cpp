@@ -213,6 +213,8 @@ int cbet_params_default(cbet_params *p, int n)
     p->kernel_variant = CBET_KERNEL_DEFAULT;
     p->lds_copies_log2 = -1;
     p->lds_prereduce = -1;
+    p->lds_corner_flip = -1;
+    p->lds_two_boxes = -1;
     return CBET_OK;
 }
 
@@ -488,10 +490,17 @@ int cbet_trace_nodes(int b, unsigned nindices, const double *ne3d, const double 
         return fail(CBET_EINVAL, "unknown kernel_variant %d", p->kernel_variant);
     int wl = p->lds_window_log2 ? p->lds_window_log2 : 3;
     if (wl != 3 && wl != 4) return fail(CBET_EINVAL, "lds_window_log2 must be 3 or 4");
-    int rl = p->lds_copies_log2 < 0 ? 1 : p->lds_copies_log2;  // auto: 2 copies (measured best)
+    // LDS_WINDOW tuning knobs; "auto" (-1) = the measured best: two boxes of one tile each,
+    // lane-dependent corner order, no privatised copies, no lane pre-reduction
+    const bool two_auto = p->lds_two_boxes < 0 && p->lds_copies_log2 <= 0 && p->lds_prereduce <= 0 &&
+                          p->lds_corner_flip != 0 && wl == 3;
+    const bool two = p->lds_two_boxes > 0 || two_auto;
+    int rl = p->lds_copies_log2 < 0 ? 0 : p->lds_copies_log2;
     if (rl > 2) return fail(CBET_EINVAL, "lds_copies_log2 must be -1 (auto) or 0..2");
     int pre = p->lds_prereduce < 0 ? 0 : p->lds_prereduce;
     if (pre > 2) return fail(CBET_EINVAL, "lds_prereduce must be -1 (auto) or 0..2");
+    if (two && (rl != 0 || pre != 0 || wl != 3 || p->lds_corner_flip == 0))
+        return fail(CBET_EINVAL, "lds_two_boxes needs lds_window_log2=3, one copy, no pre-reduction, corner flip on");
 
     const cbet_derived &d = ctx->d;
     TraceArgs a{};
@@ -523,7 +532,8 @@ int cbet_trace_nodes(int b, unsigned nindices, const double *ne3d, const double 
 
     DeviceGuard guard;
     CBET_HIP(hipSetDevice(ctx->gpu));
-    CBET_HIP(launch_trace(a, variant, wl, rl, pre, (hipStream_t)stream));
+    const bool flip = p->lds_corner_flip != 0;  // auto: on
+    CBET_HIP(launch_trace(a, variant, wl, rl, pre, flip, two, (hipStream_t)stream));
     return CBET_OK;
 }
 

@@ -69,7 +69,7 @@ struct TraceArgs {
 
 hipError_t launch_tabulate(const TabulateArgs &a, hipStream_t stream);
 hipError_t launch_trace(const TraceArgs &a, int variant, int window_log2, int copies_log2, int prereduce,
-                        hipStream_t stream);
+                        bool corner_flip, bool two_boxes, hipStream_t stream);
 
 }  // namespace cbet
 #endif

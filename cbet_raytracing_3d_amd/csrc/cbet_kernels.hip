@@ -343,9 +343,15 @@ struct MovingWindow {
     // absolute coordinate in [o, o+W) whose residue mod W is r
     static __device__ __forceinline__ int absolute(int o, int r) { return o + ((r - o) & (W - 1)); }
 
-    // Retire the slab `coord` (absolute, inside the box) of axis AX: flush non-zero sums, zero them.
-    template <int AX>
-    __device__ __forceinline__ void retire(int coord, int lane, double *edep, int sXh, int sYh, int &n_at)
+    // Retire the slab `coord` (absolute, inside the box) of axis AX: take the non-zero sums out of
+    // the tile and zero them.  For W = 8 a slab is exactly one accumulator per lane and the sum is
+    // handed back in (dv, dn) = (value, flat haloed node index) so that the caller can issue the
+    // global atomic LATER, behind the next step's gathers (loads, stores and atomics share one
+    // in-order vmcnt on CDNA: an atomic issued before a load delays that load's data by the
+    // atomic's ~3000-cycle round trip).  DEFER = false (W = 16, final flush): atomics issued here.
+    template <int AX, bool DEFER>
+    __device__ __forceinline__ void retire(int coord, int lane, double *edep, int sXh, int sYh, int &n_at,
+                                           double &dv, int &dn)
     {
         const int fixed = coord & (W - 1);
 #pragma unroll
@@ -359,9 +365,15 @@ struct MovingWindow {
 #pragma unroll
             for (int c = 1; c < R; ++c) v += val[c * CS + slot];
             if (v != 0.0) {  // only nodes that received deposits are non-zero, hence valid
+                const int node = i * sXh + j * sYh + k;
+                if (DEFER && W * W == kWave) {
+                    dv = v;
+                    dn = node;
+                } else {
 #ifndef CBET_EXPERIMENT_DROP_FLUSH_ATOMICS  // timing-only experiment builds (scripts/experiment_*.sh); never shipped
-                global_add(&edep[(long)i * sXh + (long)j * sYh + k], v);
+                    global_add(&edep[node], v);
 #endif
+                }
 #pragma unroll
                 for (int c = 0; c < R; ++c) val[c * CS + slot] = 0.0;
                 ++n_at;
@@ -370,9 +382,10 @@ struct MovingWindow {
     }
     static __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
-    template <int AX>
+    template <int AX, bool DEFER>
     __device__ __forceinline__ void follow_axis(int &o, bool alive, int lo_corner, int lane, double *edep,
-                                                int sXh, int sYh, int &n_at, int &n_wide, int &n_slabs)
+                                                int sXh, int sYh, int &n_at, int &n_wide, int &n_slabs,
+                                                double &dv, int &dn)
     {
         // dead lanes get a neutral offset (mid-box), so no ballot needs the alive mask
         const int rel = alive ? lo_corner - o : W / 2 - 1;
@@ -384,18 +397,26 @@ struct MovingWindow {
         const bool want_up = above || (at_hi && !near_lo);
         if (below && above) ++n_wide;  // wave-uniform: the bundle does not fit the box on this axis
         if (want_down && !at_hi) {
-            retire<AX>(o + W - 1, lane, edep, sXh, sYh, n_at);
+            retire<AX, DEFER>(o + W - 1, lane, edep, sXh, sYh, n_at, dv, dn);
             o -= 1;
             ++n_slabs;
         } else if (want_up && !at_lo) {
-            retire<AX>(o, lane, edep, sXh, sYh, n_at);
+            retire<AX, DEFER>(o, lane, edep, sXh, sYh, n_at, dv, dn);
             o += 1;
             ++n_slabs;
         }
     }
+    // are the lane's 8 targets (low corner lx,ly,lz and its +1 neighbours) inside the box?
+    __device__ __forceinline__ bool holds(int lx, int ly, int lz) const
+    {
+        return (unsigned)(lx - ox) <= (unsigned)S && (unsigned)(ly - oy) <= (unsigned)S &&
+               (unsigned)(lz - oz) <= (unsigned)S;
+    }
     __device__ __forceinline__ void flush_all(int lane, double *edep, int sXh, int sYh, int &n_at)
     {
-        for (int t = 0; t < W; ++t) retire<0>(ox + t, lane, edep, sXh, sYh, n_at);
+        double dv = 0.0;
+        int dn = 0;
+        for (int t = 0; t < W; ++t) retire<0, false>(ox + t, lane, edep, sXh, sYh, n_at, dv, dn);
     }
     __device__ __forceinline__ void add(int slot, double w)
     {
@@ -450,12 +471,15 @@ __device__ __forceinline__ double node_load(const double *base, unsigned idx)
 //   WL       : log2 of the LDS window edge (DEPOSIT 2, 3)
 //   RL       : log2 of the number of privatised window copies (DEPOSIT 3)
 //   PRE      : levels of in-register pre-reduction across neighbouring lanes (DEPOSIT 3; 0, 1, 2)
+//   FLIP     : lane-dependent corner order (DEPOSIT 3; see the weights section)
+//   TWOBOX   : a second window adopts the lanes that leave the first (DEPOSIT 3, RL = 0, PRE = 0)
 //   IDX64    : node tables of >= 2^32 bytes (n > 812)
 // ---------------------------------------------------------------------------------------------
-template <int DEPOSIT, int WL, int RL, int PRE, bool IDX64>
+template <int DEPOSIT, int WL, int RL, int PRE, bool FLIP, bool TWOBOX, bool IDX64>
 __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
 {
-    constexpr int NSLOT = (DEPOSIT == 3) ? MovingWindow<WL, RL>::NDOUBLES : (DEPOSIT == 2 ? (1 << (3 * WL)) : 1);
+    constexpr int NSLOT = (DEPOSIT == 3) ? (TWOBOX ? 2 : 1) * MovingWindow<WL, RL>::NDOUBLES
+                                         : (DEPOSIT == 2 ? (1 << (3 * WL)) : 1);
     constexpr int NTAG = (DEPOSIT == 2) ? NSLOT : 1;
     constexpr int W = 1 << WL;
     __shared__ double s_val[NSLOT];
@@ -483,6 +507,14 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
 
     LdsWindow<WL> tagged{s_val, s_tag};
     MovingWindow<WL, RL> win{s_val, 0, 0, 0};
+    // Second box (TWOBOX): after the turning point a bundle fans out to 6-11 cells (scripts/
+    // bundle_spread.py), wider than one 8-cell box.  Lanes that fall out of box A are adopted by
+    // box B (sticky per-lane home bit); B is created around the first such lane and flushed when
+    // its last lane leaves or dies.
+    MovingWindow<WL, RL> winB{s_val + (TWOBOX ? MovingWindow<WL, RL>::NDOUBLES : 0), 0, 0, 0};
+    bool homeB = false;     // per lane
+    bool b_active = false;  // wave-uniform
+    int w_bsteps = 0;
     if (DEPOSIT == 2) {
         tagged.clear(lane);
         __syncthreads();
@@ -493,8 +525,34 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
         const int src = ((m >> 27) & 1ull) ? 27 : (__ffsll((long long)m) - 1);
         win.init(lane, __builtin_amdgcn_readlane(s.ci, src) + 1, __builtin_amdgcn_readlane(s.cj, src) + 1,
                  __builtin_amdgcn_readlane(s.ck, src) + 1);
+        if (TWOBOX) winB.init(lane, 0, 0, 0);
         __syncthreads();
     }
+
+    // Software pipeline: the six stencil gathers of a step are issued at the END of the previous
+    // step (right after relocation, together with the kappa gather), so they are in flight during
+    // the whole deposit phase; slab-flush atomics produced by a step are issued in the NEXT step,
+    // behind that step's gathers.
+    double st_xp = 0, st_xm = 0, st_yp = 0, st_ym = 0, st_zp = 0, st_zm = 0;
+    auto gather_stencil = [&]() {
+        // :212-238 neighbours of the current node, one-sided at the faces, as table offsets
+        const int oxm = (s.ci == 0) ? 0 : ((s.ci == nx - 1) ? -2 * sX : -sX);
+        const int oxp = (s.ci == 0) ? 2 * sX : ((s.ci == nx - 1) ? 0 : sX);
+        const int oym = (s.cj == 0) ? 0 : ((s.cj == ny - 1) ? -2 * sY : -sY);
+        const int oyp = (s.cj == 0) ? 2 * sY : ((s.cj == ny - 1) ? 0 : sY);
+        const int ozm = (s.ck == 0) ? 0 : ((s.ck == nz - 1) ? -2 : -1);
+        const int ozp = (s.ck == 0) ? 2 : ((s.ck == nz - 1) ? 0 : 1);
+        // :254-265 six gathers from the node table
+        st_xp = node_load<IDX64>(a.ne3d, cell + oxp);
+        st_xm = node_load<IDX64>(a.ne3d, cell + oxm);
+        st_yp = node_load<IDX64>(a.ne3d, cell + oyp);
+        st_ym = node_load<IDX64>(a.ne3d, cell + oym);
+        st_zp = node_load<IDX64>(a.ne3d, cell + ozp);
+        st_zm = node_load<IDX64>(a.ne3d, cell + ozm);
+    };
+    if (alive) gather_stencil();
+    double dv0 = 0.0, dv1 = 0.0, dv2 = 0.0;  // deferred slab sums (one per axis) and their nodes
+    int dn0 = 0, dn1 = 0, dn2 = 0;
 
     for (int tt = 0; tt < a.nt; ++tt) {                        // :207
         const unsigned long long live_mask = __ballot(alive);
@@ -503,32 +561,20 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
         unsigned slot[8], node[8];
         double wgt[8];
         int hi = 0, hj = 0, hk = 0, sx = 1, sy = 1, sz = 1;
+        int X0 = 0, X1 = 0, Y0 = 0, Y1 = 0, Z0 = 0, Z1 = 0;
+        double fx = 0, fy = 0, fz = 0, kap = 0;
         if (alive) {
-            // :212-238 neighbours of the current node, one-sided at the faces, as table offsets
-            const int oxm = (s.ci == 0) ? 0 : ((s.ci == nx - 1) ? -2 * sX : -sX);
-            const int oxp = (s.ci == 0) ? 2 * sX : ((s.ci == nx - 1) ? 0 : sX);
-            const int oym = (s.cj == 0) ? 0 : ((s.cj == ny - 1) ? -2 * sY : -sY);
-            const int oyp = (s.cj == 0) ? 2 * sY : ((s.cj == ny - 1) ? 0 : sY);
-            const int ozm = (s.ck == 0) ? 0 : ((s.ck == nz - 1) ? -2 : -1);
-            const int ozp = (s.ck == 0) ? 2 : ((s.ck == nz - 1) ? 0 : 1);
-            // :254-265 six gathers from the node table
-            const double ne_xp = node_load<IDX64>(a.ne3d, cell + oxp);
-            const double ne_xm = node_load<IDX64>(a.ne3d, cell + oxm);
-            const double ne_yp = node_load<IDX64>(a.ne3d, cell + oyp);
-            const double ne_ym = node_load<IDX64>(a.ne3d, cell + oym);
-            const double ne_zp = node_load<IDX64>(a.ne3d, cell + ozp);
-            const double ne_zm = node_load<IDX64>(a.ne3d, cell + ozm);
-            // :268-273 kick then drift
-            s.vx -= a.xconst * (ne_xp - ne_xm);
-            s.vy -= a.yconst * (ne_yp - ne_ym);
-            s.vz -= a.zconst * (ne_zp - ne_zm);
+            // :268-273 kick then drift (stencil values gathered during the previous step)
+            s.vx -= a.xconst * (st_xp - st_xm);
+            s.vy -= a.yconst * (st_yp - st_ym);
+            s.vz -= a.zconst * (st_zp - st_zm);
             s.px += s.vx * a.dt;
             s.py += s.vy * a.dt;
             s.pz += s.vz * a.dt;
             // :276-292 position in cell units, nearest-node update
-            const double fx = (s.px - a.xmin) * a.inv_dx;
-            const double fy = (s.py - a.ymin) * a.inv_dy;
-            const double fz = (s.pz - a.zmin) * a.inv_dz;
+            fx = (s.px - a.xmin) * a.inv_dx;
+            fy = (s.py - a.ymin) * a.inv_dy;
+            fz = (s.pz - a.zmin) * a.inv_dz;
             if (DEPOSIT == 3) {
                 s.ci = relocate_closed(s.ci, fx, nx);
                 s.cj = relocate_closed(s.cj, fy, ny);
@@ -539,56 +585,79 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
                 s.ck = relocate_loop(s.ck, fz, nz);
             }
             cell = (unsigned)(__mul24(__mul24(s.ci, ny) + s.cj, nz) + s.ck);
-            // :296-311 absorption at the new node
+            // :296-298 absorption coefficient at the new node, then the NEXT step's stencil
+            if (a.absorption == 1) kap = node_load<IDX64>(a.kap3d, cell);
+            gather_stencil();
+        }
+        if (DEPOSIT == 3) {
+            // last step's retired slabs go to HBM now, younger than this step's gathers
+#ifndef CBET_EXPERIMENT_DROP_FLUSH_ATOMICS
+            if (dv0 != 0.0) { global_add(&a.edep[dn0], dv0); dv0 = 0.0; }
+            if (dv1 != 0.0) { global_add(&a.edep[dn1], dv1); dv1 = 0.0; }
+            if (dv2 != 0.0) { global_add(&a.edep[dn2], dv2); dv2 = 0.0; }
+#endif
+        }
+        if (alive) {
+            // :299-311 absorbed energy
             double inc;
             if (a.absorption == 1) {
-                inc = node_load<IDX64>(a.kap3d, cell) * s.uray;
+                inc = kap * s.uray;
                 s.uray -= inc;
             } else {
                 inc = s.uray;
             }
-            // :319-339 weights
+            // :319-339 weights.  Each weight is (Fz * Fy) * Fx * inc with F = (1-d) for the ray's own
+            // node along that axis and F = d for the neighbour on the `sign` side (:329-336).
             const double ox = fx - s.ci - 0.5, oy = fy - s.cj - 0.5, oz = fz - s.ck - 0.5;
             const double dm = 1.0 - fabs(ox), dn = 1.0 - fabs(oy), dl = 1.0 - fabs(oz);
-            const double a1 = (1.0 - dl) * (1.0 - dn) * (1.0 - dm);
-            const double a2 = (1.0 - dl) * (1.0 - dn) * dm;
-            const double a3 = dl * (1.0 - dn) * (1.0 - dm);
-            const double a4 = dl * (1.0 - dn) * dm;
-            const double a5 = (1.0 - dl) * dn * (1.0 - dm);
-            const double a6 = (1.0 - dl) * dn * dm;
-            const double a7 = dl * dn * (1.0 - dm);
-            const double a8 = dl * dn * dm;
             sx = (ox < 0) ? -1 : 1;
             sy = (oy < 0) ? -1 : 1;
             sz = (oz < 0) ? -1 : 1;
-            // :341-348 targets, reference order
             hi = s.ci + 1;
             hj = s.cj + 1;
             hk = s.ck + 1;
-            const int base = __mul24(hi, sXh) + __mul24(hj, sYh) + hk;
-            const int dX = sx * sXh, dY = sy * sYh;
-            wgt[0] = a1 * inc; node[0] = base;
-            wgt[1] = a2 * inc; node[1] = base + dX;
-            wgt[2] = a3 * inc; node[2] = base + sz;
-            wgt[3] = a4 * inc; node[3] = base + dX + sz;
-            wgt[4] = a5 * inc; node[4] = base + dY;
-            wgt[5] = a6 * inc; node[5] = base + dX + dY;
-            wgt[6] = a7 * inc; node[6] = base + dY + sz;
-            wgt[7] = a8 * inc; node[7] = base + dX + dY + sz;
+            // Corner order.  The eight (node, weight) pairs are the same whatever order they are
+            // enumerated in, and every product keeps the reference's operand order.  With FLIP, lane
+            // bits 0/1/2 swap which of an axis's two nodes is visited first, so the 8 lanes of a
+            // patch row -- rays a quarter cell apart that usually share all 8 target nodes -- hit 8
+            // different nodes in any one ds_add_f64 instead of serialising on one address.
+            const bool flx = FLIP && (lane & 1), fly = FLIP && (lane & 2), flz = FLIP && (lane & 4);
+            const double ax_own = 1.0 - dm, ay_own = 1.0 - dn, az_own = 1.0 - dl;
+            const double Fx0 = flx ? dm : ax_own, Fx1 = flx ? ax_own : dm;
+            const double Fy0 = fly ? dn : ay_own, Fy1 = fly ? ay_own : dn;
+            const double Fz0 = flz ? dl : az_own, Fz1 = flz ? az_own : dl;
+            X0 = flx ? hi + sx : hi; X1 = flx ? hi : hi + sx;
+            Y0 = fly ? hj + sy : hj; Y1 = fly ? hj : hj + sy;
+            Z0 = flz ? hk + sz : hk; Z1 = flz ? hk : hk + sz;
+            const double zy00 = Fz0 * Fy0, zy10 = Fz1 * Fy0, zy01 = Fz0 * Fy1, zy11 = Fz1 * Fy1;
+            // order (x,y,z) = (0,0,0) (1,0,0) (0,0,1) (1,0,1) (0,1,0) (1,1,0) (0,1,1) (1,1,1) -- :341-348 without FLIP
+            wgt[0] = zy00 * Fx0 * inc;
+            wgt[1] = zy00 * Fx1 * inc;
+            wgt[2] = zy10 * Fx0 * inc;
+            wgt[3] = zy10 * Fx1 * inc;
+            wgt[4] = zy01 * Fx0 * inc;
+            wgt[5] = zy01 * Fx1 * inc;
+            wgt[6] = zy11 * Fx0 * inc;
+            wgt[7] = zy11 * Fx1 * inc;
+            if (DEPOSIT != 3) {
+                const int nX0 = __mul24(X0, sXh), nX1 = __mul24(X1, sXh), nY0 = __mul24(Y0, sYh), nY1 = __mul24(Y1, sYh);
+                node[0] = nX0 + nY0 + Z0; node[1] = nX1 + nY0 + Z0; node[2] = nX0 + nY0 + Z1; node[3] = nX1 + nY0 + Z1;
+                node[4] = nX0 + nY1 + Z0; node[5] = nX1 + nY1 + Z0; node[6] = nX0 + nY1 + Z1; node[7] = nX1 + nY1 + Z1;
+            }
             if (DEPOSIT == 1) {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) global_add(&a.edep[node[c]], wgt[c]);
                 n_atomics += 8;
             }
             if (DEPOSIT == 2) {
-                slot[0] = tagged.slot(hi, hj, hk);
-                slot[1] = tagged.slot(hi + sx, hj, hk);
-                slot[2] = tagged.slot(hi, hj, hk + sz);
-                slot[3] = tagged.slot(hi + sx, hj, hk + sz);
-                slot[4] = tagged.slot(hi, hj + sy, hk);
-                slot[5] = tagged.slot(hi + sx, hj + sy, hk);
-                slot[6] = tagged.slot(hi, hj + sy, hk + sz);
-                slot[7] = tagged.slot(hi + sx, hj + sy, hk + sz);
+                slot[0] = tagged.slot(X0, Y0, Z0);
+                slot[1] = tagged.slot(X1, Y0, Z0);
+                slot[2] = tagged.slot(X0, Y0, Z1);
+                slot[3] = tagged.slot(X1, Y0, Z1);
+                slot[4] = tagged.slot(X0, Y1, Z0);
+                slot[5] = tagged.slot(X1, Y1, Z0);
+                slot[6] = tagged.slot(X0, Y1, Z1);
+                slot[7] = tagged.slot(X1, Y1, Z1);
             }
             ++nsteps;
         }
@@ -597,27 +666,79 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
             // the lane's 8 targets span {h, h+s} per axis; its low corner is h + (s>>1)  (s>>1: -1 or 0)
             const int ax = hi + (sx >> 1), ay = hj + (sy >> 1), az = hk + (sz >> 1);
             int wide = 0;
-            win.template follow_axis<0>(win.ox, alive, ax, lane, a.edep, sXh, sYh, n_atomics, wide, w_slabs);
-            win.template follow_axis<1>(win.oy, alive, ay, lane, a.edep, sXh, sYh, n_atomics, wide, w_slabs);
-            win.template follow_axis<2>(win.oz, alive, az, lane, a.edep, sXh, sYh, n_atomics, wide, w_slabs);
-            __builtin_amdgcn_wave_barrier();
-            const bool inbox = alive && (unsigned)(ax - win.ox) <= (unsigned)(W - 2) &&
-                               (unsigned)(ay - win.oy) <= (unsigned)(W - 2) &&
-                               (unsigned)(az - win.oz) <= (unsigned)(W - 2);
+            using MW = MovingWindow<WL, RL>;
+            bool inbox;            // the lane deposits into LDS this step
+            int tile = 0;          // ... into this tile (offset in doubles)
+            if (!TWOBOX) {
+                win.template follow_axis<0, true>(win.ox, alive, ax, lane, a.edep, sXh, sYh, n_atomics, wide, w_slabs, dv0, dn0);
+                win.template follow_axis<1, true>(win.oy, alive, ay, lane, a.edep, sXh, sYh, n_atomics, wide, w_slabs, dv1, dn1);
+                win.template follow_axis<2, true>(win.oz, alive, az, lane, a.edep, sXh, sYh, n_atomics, wide, w_slabs, dv2, dn2);
+                __builtin_amdgcn_wave_barrier();
+                inbox = alive && win.holds(ax, ay, az);
+            } else {
+                // box A follows the lanes whose home it is
+                const bool memA = alive && !homeB;
+                win.template follow_axis<0, true>(win.ox, memA, ax, lane, a.edep, sXh, sYh, n_atomics, wide, w_slabs, dv0, dn0);
+                win.template follow_axis<1, true>(win.oy, memA, ay, lane, a.edep, sXh, sYh, n_atomics, wide, w_slabs, dv1, dn1);
+                win.template follow_axis<2, true>(win.oz, memA, az, lane, a.edep, sXh, sYh, n_atomics, wide, w_slabs, dv2, dn2);
+                const bool inA = alive && win.holds(ax, ay, az);
+                bool inB = false;
+                if (b_active) {  // scalar branch
+                    ++w_bsteps;
+                    const bool memB = alive && homeB;
+                    double tv = 0.0;
+                    int tn = 0, tw = 0;
+                    winB.template follow_axis<0, false>(winB.ox, memB, ax, lane, a.edep, sXh, sYh, n_atomics, tw, w_slabs, tv, tn);
+                    winB.template follow_axis<1, false>(winB.oy, memB, ay, lane, a.edep, sXh, sYh, n_atomics, tw, w_slabs, tv, tn);
+                    winB.template follow_axis<2, false>(winB.oz, memB, az, lane, a.edep, sXh, sYh, n_atomics, tw, w_slabs, tv, tn);
+                    inB = alive && winB.holds(ax, ay, az);
+                }
+                // lanes that fell out of A look for a home in B; an idle B is re-created around the first of them
+                const bool lost = alive && !homeB && !inA;
+                const unsigned long long lost_mask = __builtin_amdgcn_ballot_w64(lost);
+                if (lost_mask != 0ull) {
+                    if (!b_active) {
+                        const int src = __ffsll((long long)lost_mask) - 1;
+                        winB.ox = __builtin_amdgcn_readlane(ax, src) - (W / 2 - 1);
+                        winB.oy = __builtin_amdgcn_readlane(ay, src) - (W / 2 - 1);
+                        winB.oz = __builtin_amdgcn_readlane(az, src) - (W / 2 - 1);
+                        b_active = true;  // its tile is all zero: zeroed at start and flushed whenever it empties
+                        inB = alive && winB.holds(ax, ay, az);
+                    }
+                    homeB = homeB || (lost && inB);
+                }
+                if (b_active) {
+                    // a B lane that drifted out of B but back into A goes home
+                    if (alive && homeB && !inB && inA) homeB = false;
+                    if (__builtin_amdgcn_ballot_w64(alive && homeB) == 0ull) {
+                        __builtin_amdgcn_wave_barrier();
+                        winB.flush_all(lane, a.edep, sXh, sYh, n_atomics);
+                        b_active = false;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                const bool useB = alive && homeB && inB;
+                inbox = useB || (alive && !homeB && inA);
+                tile = useB ? MW::NDOUBLES : 0;
+            }
             if (__builtin_amdgcn_ballot_w64(alive && !inbox) != 0ull) {
                 ++w_miss;
                 w_wide += wide ? 1 : 0;
             }
-            // key: identifies the ordered set of 8 target nodes (base node + the three signs)
-            int key = inbox ? (int)((node[0] << 3) | ((sx & 2) << 1) | (sy & 2) | ((sz & 2) >> 1)) : -2 - lane;
-            if (PRE >= 1) merge_level<0xB1, 1>(lane, key, wgt);   // quad_perm [1,0,3,2]: lane ^ 1
-            if (PRE >= 2) merge_level<0x4E, 2>(lane, key, wgt);   // quad_perm [2,3,0,1]: lane ^ 2
+            // key: identifies the ordered set of 8 target nodes (own node + the three signs); lanes may
+            // only be merged when they enumerate the corners in the same order, i.e. without FLIP
+            int key = inbox ? 0 : -2 - lane;
+            if (PRE >= 1 && !FLIP) {
+                if (inbox)
+                    key = (int)(((__mul24(hi, sXh) + __mul24(hj, sYh) + hk) << 3) | ((sx & 2) << 1) | (sy & 2) | ((sz & 2) >> 1));
+                merge_level<0xB1, 1>(lane, key, wgt);                 // quad_perm [1,0,3,2]: lane ^ 1
+                if (PRE >= 2) merge_level<0x4E, 2>(lane, key, wgt);   // quad_perm [2,3,0,1]: lane ^ 2
+            }
             if (key >= 0) {
-                using MW = MovingWindow<WL, RL>;
-                const int copy = ((lane >> PRE) & (MW::R - 1)) * MW::CS;
-                const int x0 = (hi & (W - 1)) * MW::XS + copy, x1 = ((hi + sx) & (W - 1)) * MW::XS + copy;
-                const int y0 = (hj & (W - 1)) * MW::YS, y1 = ((hj + sy) & (W - 1)) * MW::YS;
-                const int z0 = hk & (W - 1), z1 = (hk + sz) & (W - 1);
+                const int copy = ((lane >> PRE) & (MW::R - 1)) * MW::CS + tile;
+                const int x0 = (X0 & (W - 1)) * MW::XS + copy, x1 = (X1 & (W - 1)) * MW::XS + copy;
+                const int y0 = (Y0 & (W - 1)) * MW::YS, y1 = (Y1 & (W - 1)) * MW::YS;
+                const int z0 = Z0 & (W - 1), z1 = Z1 & (W - 1);
                 win.add(x0 + y0 + z0, wgt[0]);
                 win.add(x1 + y0 + z0, wgt[1]);
                 win.add(x0 + y0 + z1, wgt[2]);
@@ -627,8 +748,17 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
                 win.add(x0 + y1 + z1, wgt[6]);
                 win.add(x1 + y1 + z1, wgt[7]);
             } else if (alive && !inbox) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) global_add(&a.edep[node[c]], wgt[c]);
+#ifndef CBET_EXPERIMENT_DROP_MISS_ATOMICS  // timing-only experiment builds; never shipped
+                const int nX0 = __mul24(X0, sXh), nX1 = __mul24(X1, sXh), nY0 = __mul24(Y0, sYh), nY1 = __mul24(Y1, sYh);
+                global_add(&a.edep[nX0 + nY0 + Z0], wgt[0]);
+                global_add(&a.edep[nX1 + nY0 + Z0], wgt[1]);
+                global_add(&a.edep[nX0 + nY0 + Z1], wgt[2]);
+                global_add(&a.edep[nX1 + nY0 + Z1], wgt[3]);
+                global_add(&a.edep[nX0 + nY1 + Z0], wgt[4]);
+                global_add(&a.edep[nX1 + nY1 + Z0], wgt[5]);
+                global_add(&a.edep[nX0 + nY1 + Z1], wgt[6]);
+                global_add(&a.edep[nX1 + nY1 + Z1], wgt[7]);
+#endif
                 n_atomics += 8;
                 ++n_evict;  // counted as "ray-steps that missed the window"
             }
@@ -645,8 +775,12 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
         n_atomics += tagged.flush(lane, a.edep) + n_evict;
     }
     if (DEPOSIT == 3) {
+        if (dv0 != 0.0) global_add(&a.edep[dn0], dv0);
+        if (dv1 != 0.0) global_add(&a.edep[dn1], dv1);
+        if (dv2 != 0.0) global_add(&a.edep[dn2], dv2);
         __syncthreads();
         win.flush_all(lane, a.edep, sXh, sYh, n_atomics);
+        if (TWOBOX && b_active) winB.flush_all(lane, a.edep, sXh, sYh, n_atomics);
     }
     // counters: one atomic per wave and counter
     const int tot_steps = wave_sum(nsteps), tot_rays = wave_sum(launched), tot_at = wave_sum(n_atomics),
@@ -659,7 +793,7 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
         atomicAdd(&a.counters[kCntWaveSteps], (unsigned long long)w_steps);
         if (DEPOSIT == 3) {
             atomicAdd(&a.counters[kCntWaveStepsMiss], (unsigned long long)w_miss);
-            atomicAdd(&a.counters[kCntWaveStepsWide], (unsigned long long)w_wide);
+            atomicAdd(&a.counters[kCntWaveStepsWide], (unsigned long long)(TWOBOX ? w_bsteps : w_wide));
             atomicAdd(&a.counters[kCntSlabsRetired], (unsigned long long)w_slabs);
         }
     }
@@ -677,40 +811,49 @@ hipError_t launch_tabulate(const TabulateArgs &a, hipStream_t stream)
     return hipGetLastError();
 }
 
-template <int RL, int PRE, bool IDX64>
+template <int RL, int PRE, bool FLIP, bool IDX64>
 static void launch_window8(const TraceArgs &a, dim3 grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL((k_trace<3, 3, RL, PRE, IDX64>), grid, dim3(kWave), 0, stream, a);
+    hipLaunchKernelGGL((k_trace<3, 3, RL, PRE, FLIP, false, IDX64>), grid, dim3(kWave), 0, stream, a);
 }
 
 template <bool IDX64>
-static void dispatch_trace(const TraceArgs &a, int variant, int wl, int rl, int pre, dim3 grid, hipStream_t stream)
+static void dispatch_trace(const TraceArgs &a, int variant, int wl, int rl, int pre, bool flip, bool twobox,
+                           dim3 grid, hipStream_t stream)
 {
     const dim3 block(kWave);
     if (variant == CBET_KERNEL_GLOBAL_ATOMICS) {
-        hipLaunchKernelGGL((k_trace<1, 1, 0, 0, IDX64>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((k_trace<1, 1, 0, 0, false, false, IDX64>), grid, block, 0, stream, a);
     } else if (variant == CBET_KERNEL_LDS_COMBINE) {
-        if (wl == 4) hipLaunchKernelGGL((k_trace<2, 4, 0, 0, IDX64>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((k_trace<2, 3, 0, 0, IDX64>), grid, block, 0, stream, a);
+        if (wl == 4) hipLaunchKernelGGL((k_trace<2, 4, 0, 0, false, false, IDX64>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((k_trace<2, 3, 0, 0, false, false, IDX64>), grid, block, 0, stream, a);
     } else if (wl == 4) {
-        hipLaunchKernelGGL((k_trace<3, 4, 0, 0, IDX64>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((k_trace<3, 4, 0, 0, false, false, IDX64>), grid, block, 0, stream, a);
+    } else if (twobox) {
+        hipLaunchKernelGGL((k_trace<3, 3, 0, 0, true, true, IDX64>), grid, block, 0, stream, a);
+    } else if (flip) {
+        switch (rl) {
+        case 0: launch_window8<0, 0, true, IDX64>(a, grid, stream); break;
+        case 1: launch_window8<1, 0, true, IDX64>(a, grid, stream); break;
+        default: launch_window8<2, 0, true, IDX64>(a, grid, stream); break;
+        }
     } else {
         switch (rl * 3 + pre) {
-        case 0: launch_window8<0, 0, IDX64>(a, grid, stream); break;
-        case 1: launch_window8<0, 1, IDX64>(a, grid, stream); break;
-        case 2: launch_window8<0, 2, IDX64>(a, grid, stream); break;
-        case 3: launch_window8<1, 0, IDX64>(a, grid, stream); break;
-        case 4: launch_window8<1, 1, IDX64>(a, grid, stream); break;
-        case 5: launch_window8<1, 2, IDX64>(a, grid, stream); break;
-        case 6: launch_window8<2, 0, IDX64>(a, grid, stream); break;
-        case 7: launch_window8<2, 1, IDX64>(a, grid, stream); break;
-        default: launch_window8<2, 2, IDX64>(a, grid, stream); break;
+        case 0: launch_window8<0, 0, false, IDX64>(a, grid, stream); break;
+        case 1: launch_window8<0, 1, false, IDX64>(a, grid, stream); break;
+        case 2: launch_window8<0, 2, false, IDX64>(a, grid, stream); break;
+        case 3: launch_window8<1, 0, false, IDX64>(a, grid, stream); break;
+        case 4: launch_window8<1, 1, false, IDX64>(a, grid, stream); break;
+        case 5: launch_window8<1, 2, false, IDX64>(a, grid, stream); break;
+        case 6: launch_window8<2, 0, false, IDX64>(a, grid, stream); break;
+        case 7: launch_window8<2, 1, false, IDX64>(a, grid, stream); break;
+        default: launch_window8<2, 2, false, IDX64>(a, grid, stream); break;
         }
     }
 }
 
 hipError_t launch_trace(const TraceArgs &a, int variant, int window_log2, int copies_log2, int prereduce,
-                        hipStream_t stream)
+                        bool corner_flip, bool two_boxes, hipStream_t stream)
 {
     const long waves = (a.total_bundles - a.shard_index + a.shard_count - 1) / a.shard_count;
     if (waves <= 0) return hipSuccess;
@@ -718,8 +861,9 @@ hipError_t launch_trace(const TraceArgs &a, int variant, int window_log2, int co
     const bool idx64 = (unsigned long long)a.nx * a.ny * a.nz * 8ull >= (1ull << 32);
     // the pre-reduction key packs (flat haloed node index << 3 | signs) into 31 bits
     if ((long)(a.nx + 2) * (a.ny + 2) * (a.nz + 2) >= (1L << 28)) prereduce = 0;
-    if (idx64) dispatch_trace<true>(a, variant, window_log2, copies_log2, prereduce, grid, stream);
-    else dispatch_trace<false>(a, variant, window_log2, copies_log2, prereduce, grid, stream);
+    const bool flip = prereduce == 0 && corner_flip;
+    if (idx64) dispatch_trace<true>(a, variant, window_log2, copies_log2, prereduce, flip, two_boxes, grid, stream);
+    else dispatch_trace<false>(a, variant, window_log2, copies_log2, prereduce, flip, two_boxes, grid, stream);
     return hipGetLastError();
 }
 

@@ -54,7 +54,7 @@ class RayTracer:
 
     def launch(self, edep, shard_index=0, shard_count=1, beam_lo=0, beam_hi=None,
                kernel_variant=None, lds_window_log2=None, lds_copies_log2=None, lds_prereduce=None,
-               use_host_trig=True):
+               lds_corner_flip=None, lds_two_boxes=None, use_host_trig=True):
         """Enqueue one launch_ray_XYZ on torch's current stream, accumulating into `edep`."""
         if edep.dtype != torch.float64 or not edep.is_contiguous() or tuple(edep.shape) != self.grid_shape:
             raise ValueError("edep must be a contiguous float64 tensor of shape %s" % (self.grid_shape,))
@@ -69,6 +69,10 @@ class RayTracer:
             p.lds_copies_log2 = lds_copies_log2
         if lds_prereduce is not None:
             p.lds_prereduce = lds_prereduce
+        if lds_corner_flip is not None:
+            p.lds_corner_flip = lds_corner_flip
+        if lds_two_boxes is not None:
+            p.lds_two_boxes = lds_two_boxes
         d = self.derived
         stream = torch.cuda.current_stream(self.device).cuda_stream
         api.launch_ray_XYZ(0, d.nindices, self.d_te, self.d_r, self.d_ne, edep,

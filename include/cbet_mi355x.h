@@ -66,7 +66,10 @@ typedef struct cbet_params {
     int lds_window_log2;         /* LDS variants: log2 of the cubic window edge (3 or 4; 0=auto)*/
     int lds_copies_log2;         /* LDS_WINDOW: log2 of privatised tile copies (0..2; -1 = auto)*/
     int lds_prereduce;           /* LDS_WINDOW: levels of in-register lane merging (0..2; -1 = auto)*/
-    int reserved[4];
+    int lds_corner_flip;         /* LDS_WINDOW: lane-dependent corner order (0/1; -1 = auto)   */
+    int lds_two_boxes;           /* LDS_WINDOW: second window for lanes that leave the first   */
+                                 /* (0/1; -1 = auto; implies 1 copy, no pre-reduction, flip)   */
+    int reserved[2];
 } cbet_params;
 
 /* Quantities the reference derives in def.cuh / main.cu:156-161, evaluated in the same order. */
@@ -95,7 +98,8 @@ typedef struct cbet_counters {
                                          /* LDS_WINDOW: ray-steps that fell outside the window */
     unsigned long long wave_steps;       /* integrator iterations per wavefront (64 lane slots each) */
     unsigned long long wave_steps_miss;  /* LDS_WINDOW: wave-steps in which some lane missed the window */
-    unsigned long long wave_steps_wide;  /* LDS_WINDOW: of those, the bundle was wider than the window  */
+    unsigned long long wave_steps_wide;  /* LDS_WINDOW: of those, the bundle was wider than the window; */
+                                         /* with two boxes: wave-steps in which the second box was live */
     unsigned long long slabs_retired;    /* LDS_WINDOW: window slabs flushed because the box moved      */
 } cbet_counters;
 

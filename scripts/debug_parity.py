@@ -13,12 +13,12 @@ r, ne, te = api.load_s83177(); bn = api.omega60_beam_norm()[:nb]
 tr = RayTracer(api.default_params(n, nbeams=nb), r, ne, te, beam_norm=bn)
 want, steps = O.trace(O.default_config(n, nbeams=nb), bn.copy(), r, ne, te, nthreads=16)
 ne3d,kap = tr.node_tables() if False else (None,None)
-for v, w, cp, pre in ((1,0,0,0),(2,3,0,0),(3,3,0,0),(3,3,1,0),(3,3,1,1),(3,3,1,2),(3,3,0,2),(3,4,0,0)):
+for v, w, cp, pre, fl, tb in ((1,0,0,0,0,0),(2,3,0,0,0,0),(3,3,0,0,1,1),(3,3,0,0,1,0),(3,3,1,0,1,0),(3,3,1,1,0,0),(3,4,0,0,0,0)):
     e = tr.new_grid(); tr.counters(reset=True)
-    tr.launch(e, kernel_variant=v, lds_window_log2=w or None, lds_copies_log2=cp, lds_prereduce=pre)
+    tr.launch(e, kernel_variant=v, lds_window_log2=w or None, lds_copies_log2=cp, lds_prereduce=pre, lds_corner_flip=fl, lds_two_boxes=tb)
     c = tr.counters(reset=True); g = e.cpu().numpy()
     pe = perr(g, want); i = np.unravel_index(pe.argmax(), pe.shape)
-    print("variant", v, "w", w, "copies", 1<<cp, "pre", pre, "steps", c.ray_steps, steps, "rays", c.rays_traced, "atomics", c.global_atomics,
+    print("variant", v, "w", w, "copies", 1<<cp, "pre", pre, "flip", fl, "twobox", tb, "steps", c.ray_steps, steps, "rays", c.rays_traced, "atomics", c.global_atomics,
           "evict", c.lds_evictions, "err %.3e"%pe.max(), "at", i, g[i], want[i],
           "sum ratio %.15f"%(g.sum()/want.sum()), "nbad", int((pe>1e-9).sum()), "of", pe.size)
     bad = np.argwhere(pe>1e-9)

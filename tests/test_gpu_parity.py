@@ -342,3 +342,36 @@ def test_trace_with_caller_supplied_node_tables(api, oracle, inputs, torch_cuda)
     assert parity_err(got2[30:], got[30:]) < 1e-11
     assert abs(got2[:22].sum() / got[:22].sum() - 1) > 1e-3
     tr.close()
+
+
+WINDOW_CONFIGS = [  # (lds_window_log2, lds_copies_log2, lds_prereduce, lds_corner_flip, lds_two_boxes)
+    (3, 0, 0, 1, 1),    # the default: two boxes, flipped corner order
+    (3, 0, 0, 1, 0), (3, 0, 0, 0, 0), (3, 1, 0, 1, 0), (3, 2, 0, 0, 0),
+    (3, 0, 1, 0, 0), (3, 1, 2, 0, 0), (4, 0, 0, 0, 0),
+]
+
+
+@pytest.mark.parametrize("cfg", WINDOW_CONFIGS)
+def test_every_window_configuration_is_parity_exact(api, oracle, inputs, torch_cuda, cfg):
+    """All tuning knobs of the LDS_WINDOW kernel only reorder fp64 sums: same grid, same step count."""
+    bn, r, ne, te = inputs
+    beams = [0, 7, 19, 23, 31, 38, 44, 52, 57, 59]
+    tr = make_tracer(api, inputs, 56, beams=beams)
+    wl, cp, pre, fl, tb = cfg
+    e, c = run(tr, torch_cuda, kernel_variant=3, lds_window_log2=wl, lds_copies_log2=cp,
+               lds_prereduce=pre, lds_corner_flip=fl, lds_two_boxes=tb)
+    oe, osteps = oracle.trace(oracle.default_config(56, nbeams=len(beams)), bn[beams].copy(), r, ne, te,
+                              nthreads=NCPU)
+    assert c.ray_steps == osteps
+    assert parity_err(e, oe) < PARITY_TOL
+    assert c.global_atomics < 0.6 * c.ray_steps          # the window really combines
+    tr.close()
+
+
+def test_two_box_argument_validation(api, inputs, torch_cuda):
+    tr = make_tracer(api, inputs, 32, nbeams=2)
+    e = tr.new_grid()
+    with pytest.raises(api.CbetError) as ei:
+        tr.launch(e, kernel_variant=3, lds_two_boxes=1, lds_copies_log2=1)
+    assert ei.value.code == api.EINVAL
+    tr.close()
