@@ -183,6 +183,7 @@ struct cbet_context {
     cbet_derived d{};
     double *ne3d = nullptr, *kap3d = nullptr;
     double *xlaunch = nullptr, *ylaunch = nullptr;
+    double *bounds = nullptr;  // {xlo,xhi,ylo,yhi,zlo,zhi}
     int *live = nullptr;
     int nlive = 0;  // launch-list slots (64 per bundle, holes included)
     unsigned long long *counters = nullptr;
@@ -345,6 +346,7 @@ int cbet_context_destroy(cbet_context *ctx)
     (void)hipFree(ctx->kap3d);
     (void)hipFree(ctx->xlaunch);
     (void)hipFree(ctx->ylaunch);
+    (void)hipFree(ctx->bounds);
     (void)hipFree(ctx->live);
     (void)hipFree(ctx->counters);
     delete ctx;
@@ -384,6 +386,13 @@ int cbet_context_create(cbet_context **out, const cbet_params *p, int gpu)
     if ((e = hipMalloc((void **)&ctx->kap3d, nodes * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(kappa3d)");
     if ((e = hipMalloc((void **)&ctx->xlaunch, xl.size() * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(xlaunch)");
     if ((e = hipMalloc((void **)&ctx->ylaunch, yl.size() * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(ylaunch)");
+    if ((e = hipMalloc((void **)&ctx->bounds, 6 * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(bounds)");
+    {
+        // launch_ray_XZ.cu:352-354: xmin - (dx / 2.0), xmax + (dx / 2.0), ...
+        const double hb[6] = {p->xmin - (d.dx / 2.0), p->xmax + (d.dx / 2.0), p->ymin - (d.dy / 2.0),
+                              p->ymax + (d.dy / 2.0), p->zmin - (d.dz / 2.0), p->zmax + (d.dz / 2.0)};
+        if ((e = hipMemcpy(ctx->bounds, hb, sizeof hb, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(bounds)");
+    }
     if ((e = hipMalloc((void **)&ctx->live, std::max<size_t>(1, live.size()) * sizeof(int))) != hipSuccess) return bail(e, "hipMalloc(live)");
     if ((e = hipMalloc((void **)&ctx->counters, kCntSlots * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(counters)");
     if ((e = hipMemcpy(ctx->xlaunch, xl.data(), xl.size() * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(xlaunch)");
@@ -508,9 +517,8 @@ int cbet_trace_nodes(int b, unsigned nindices, const double *ne3d, const double 
     a.xmin = p->xmin; a.ymin = p->ymin; a.zmin = p->zmin;
     a.dx = d.dx; a.dy = d.dy; a.dz = d.dz; a.dt = d.dt;
     a.inv_dx = 1 / d.dx; a.inv_dy = 1 / d.dy; a.inv_dz = 1 / d.dz;      // launch_ray_XZ.cu:276-278
-    a.xlo = p->xmin - (d.dx / 2.0); a.xhi = p->xmax + (d.dx / 2.0);      // :352
-    a.ylo = p->ymin - (d.dy / 2.0); a.yhi = p->ymax + (d.dy / 2.0);      // :353
-    a.zlo = p->zmin - (d.dz / 2.0); a.zhi = p->zmax + (d.dz / 2.0);      // :354
+    a.fx_hi = p->nx - 3.0; a.fy_hi = p->ny - 3.0; a.fz_hi = p->nz - 3.0;
+    a.bounds = ctx->bounds;                                              // :352-354, see context_create
     a.tol_x = 0.5001 * d.dx; a.tol_y = 0.5001 * d.dy; a.tol_z = 0.5001 * d.dz;  // :164-176
     a.xconst = xconst; a.yconst = yconst; a.zconst = zconst;
     a.nt = d.nt; a.absorption = p->absorption;
@@ -533,7 +541,7 @@ int cbet_trace_nodes(int b, unsigned nindices, const double *ne3d, const double 
     DeviceGuard guard;
     CBET_HIP(hipSetDevice(ctx->gpu));
     const bool flip = p->lds_corner_flip != 0;  // auto: on
-    CBET_HIP(launch_trace(a, variant, wl, rl, pre, flip, two, (hipStream_t)stream));
+    CBET_HIP(launch_trace(a, variant, wl, rl, pre, flip, two, p->force_wide_index != 0, (hipStream_t)stream));
     return CBET_OK;
 }
 

@@ -45,7 +45,8 @@ struct TraceArgs {
     double xmin, ymin, zmin;
     double dx, dy, dz, dt;
     double inv_dx, inv_dy, inv_dz;          // (1/dx) of launch_ray_XZ.cu:276-278
-    double xlo, xhi, ylo, yhi, zlo, zhi;    // xmin-(dx/2.0) ... of launch_ray_XZ.cu:352-354
+    double fx_hi, fy_hi, fz_hi;             // n - 3: cell-unit positions beyond it are "near a face"
+    const double *bounds;                   // device: {xlo,xhi,ylo,yhi,zlo,zhi} = xmin-(dx/2.0) ... launch_ray_XZ.cu:352-354
     double tol_x, tol_y, tol_z;             // 0.5001*dx of launch_ray_XZ.cu:164-176
     double xconst, yconst, zconst;          // main.cu:156-159
     int nt, absorption;
@@ -69,7 +70,7 @@ struct TraceArgs {
 
 hipError_t launch_tabulate(const TabulateArgs &a, hipStream_t stream);
 hipError_t launch_trace(const TraceArgs &a, int variant, int window_log2, int copies_log2, int prereduce,
-                        bool corner_flip, bool two_boxes, hipStream_t stream);
+                        bool corner_flip, bool two_boxes, bool force_idx64, hipStream_t stream);
 
 }  // namespace cbet
 #endif

@@ -384,7 +384,7 @@ struct MovingWindow {
 
     template <int AX, bool DEFER>
     __device__ __forceinline__ void follow_axis(int &o, bool alive, int lo_corner, int lane, double *edep,
-                                                int sXh, int sYh, int &n_at, int &n_wide, int &n_slabs,
+                                                int sXh, int sYh, int &n_at, int &n_wide, unsigned &n_slabs16,
                                                 double &dv, int &dn)
     {
         // dead lanes get a neutral offset (mid-box), so no ballot needs the alive mask
@@ -399,11 +399,11 @@ struct MovingWindow {
         if (want_down && !at_hi) {
             retire<AX, DEFER>(o + W - 1, lane, edep, sXh, sYh, n_at, dv, dn);
             o -= 1;
-            ++n_slabs;
+            n_slabs16 += 1u << 16;  // packed: slabs retired in the high half
         } else if (want_up && !at_lo) {
             retire<AX, DEFER>(o, lane, edep, sXh, sYh, n_at, dv, dn);
             o += 1;
-            ++n_slabs;
+            n_slabs16 += 1u << 16;  // packed: slabs retired in the high half
         }
     }
     // are the lane's 8 targets (low corner lx,ly,lz and its +1 neighbours) inside the box?
@@ -503,7 +503,9 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
     const int sYh = nz + 2, sXh = (ny + 2) * (nz + 2);    // haloed edep strides (:5-7)
     unsigned cell = alive ? (unsigned)((s.ci * ny + s.cj) * nz + s.ck) : 0u;
     int nsteps = 0, n_atomics = 0, n_evict = 0;
-    int w_steps = 0, w_miss = 0, w_wide = 0, w_slabs = 0;  // wave-uniform diagnostics
+    // wave-uniform diagnostics, packed two to a scalar register (each < 2^16: nt <= 4 n)
+    unsigned w_steps_miss = 0;   // wave-steps << 16 | wave-steps with a window miss
+    unsigned w_slabs_wide = 0;   // slabs retired << 16 | wave-steps "too wide" (two boxes: box B live)
 
     LdsWindow<WL> tagged{s_val, s_tag};
     MovingWindow<WL, RL> win{s_val, 0, 0, 0};
@@ -514,7 +516,7 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
     MovingWindow<WL, RL> winB{s_val + (TWOBOX ? MovingWindow<WL, RL>::NDOUBLES : 0), 0, 0, 0};
     bool homeB = false;     // per lane
     bool b_active = false;  // wave-uniform
-    int w_bsteps = 0;
+
     if (DEPOSIT == 2) {
         tagged.clear(lane);
         __syncthreads();
@@ -534,14 +536,23 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
     // the whole deposit phase; slab-flush atomics produced by a step are issued in the NEXT step,
     // behind that step's gathers.
     double st_xp = 0, st_xm = 0, st_yp = 0, st_ym = 0, st_zp = 0, st_zm = 0;
+    bool wave_on_face = true;  // wave-uniform: some lane's current cell lies on a grid face
     auto gather_stencil = [&]() {
-        // :212-238 neighbours of the current node, one-sided at the faces, as table offsets
-        const int oxm = (s.ci == 0) ? 0 : ((s.ci == nx - 1) ? -2 * sX : -sX);
-        const int oxp = (s.ci == 0) ? 2 * sX : ((s.ci == nx - 1) ? 0 : sX);
-        const int oym = (s.cj == 0) ? 0 : ((s.cj == ny - 1) ? -2 * sY : -sY);
-        const int oyp = (s.cj == 0) ? 2 * sY : ((s.cj == ny - 1) ? 0 : sY);
-        const int ozm = (s.ck == 0) ? 0 : ((s.ck == nz - 1) ? -2 : -1);
-        const int ozp = (s.ck == 0) ? 2 : ((s.ck == nz - 1) ? 0 : 1);
+        // :212-238 neighbours of the current node as table offsets.  Interior cells (every lane of
+        // the wave, almost always) use the plain +-1 neighbours; the one-sided face rule is a rare,
+        // wave-uniform branch.
+        const bool on_face = (unsigned)(s.ci - 1) >= (unsigned)(nx - 2) || (unsigned)(s.cj - 1) >= (unsigned)(ny - 2) ||
+                             (unsigned)(s.ck - 1) >= (unsigned)(nz - 2);
+        int oxm = -sX, oxp = sX, oym = -sY, oyp = sY, ozm = -1, ozp = 1;
+        wave_on_face = __builtin_amdgcn_ballot_w64(on_face) != 0ull;
+        if (wave_on_face) {
+            oxm = (s.ci == 0) ? 0 : ((s.ci == nx - 1) ? -2 * sX : -sX);
+            oxp = (s.ci == 0) ? 2 * sX : ((s.ci == nx - 1) ? 0 : sX);
+            oym = (s.cj == 0) ? 0 : ((s.cj == ny - 1) ? -2 * sY : -sY);
+            oyp = (s.cj == 0) ? 2 * sY : ((s.cj == ny - 1) ? 0 : sY);
+            ozm = (s.ck == 0) ? 0 : ((s.ck == nz - 1) ? -2 : -1);
+            ozp = (s.ck == 0) ? 2 : ((s.ck == nz - 1) ? 0 : 1);
+        }
         // :254-265 six gathers from the node table
         st_xp = node_load<IDX64>(a.ne3d, cell + oxp);
         st_xm = node_load<IDX64>(a.ne3d, cell + oxm);
@@ -557,7 +568,7 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
     for (int tt = 0; tt < a.nt; ++tt) {                        // :207
         const unsigned long long live_mask = __ballot(alive);
         if (live_mask == 0) break;
-        ++w_steps;
+        w_steps_miss += 1u << 16;
         unsigned slot[8], node[8];
         double wgt[8];
         int hi = 0, hj = 0, hk = 0, sx = 1, sy = 1, sz = 1;
@@ -576,9 +587,21 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
             fy = (s.py - a.ymin) * a.inv_dy;
             fz = (s.pz - a.zmin) * a.inv_dz;
             if (DEPOSIT == 3) {
-                s.ci = relocate_closed(s.ci, fx, nx);
-                s.cj = relocate_closed(s.cj, fy, ny);
-                s.ck = relocate_closed(s.ck, fz, nz);
+                // fast path: interior cells, unambiguous matches (cbet_relocate.h); one ballot covers
+                // all three axes, and `wave_on_face` was evaluated for this very cell by gather_stencil
+                bool amb = false;
+                const int qi = relocate_fast_interior(s.ci, fx, amb);
+                const int qj = relocate_fast_interior(s.cj, fy, amb);
+                const int qk = relocate_fast_interior(s.ck, fz, amb);
+                if (wave_on_face || __builtin_amdgcn_ballot_w64(amb) != 0ull) {
+                    s.ci = relocate_closed(s.ci, fx, nx);
+                    s.cj = relocate_closed(s.cj, fy, ny);
+                    s.ck = relocate_closed(s.ck, fz, nz);
+                } else {
+                    s.ci = qi;
+                    s.cj = qj;
+                    s.ck = qk;
+                }
             } else {
                 s.ci = relocate_loop(s.ci, fx, nx);
                 s.cj = relocate_loop(s.cj, fy, ny);
@@ -670,27 +693,27 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
             bool inbox;            // the lane deposits into LDS this step
             int tile = 0;          // ... into this tile (offset in doubles)
             if (!TWOBOX) {
-                win.template follow_axis<0, true>(win.ox, alive, ax, lane, a.edep, sXh, sYh, n_atomics, wide, w_slabs, dv0, dn0);
-                win.template follow_axis<1, true>(win.oy, alive, ay, lane, a.edep, sXh, sYh, n_atomics, wide, w_slabs, dv1, dn1);
-                win.template follow_axis<2, true>(win.oz, alive, az, lane, a.edep, sXh, sYh, n_atomics, wide, w_slabs, dv2, dn2);
+                win.template follow_axis<0, true>(win.ox, alive, ax, lane, a.edep, sXh, sYh, n_atomics, wide, w_slabs_wide, dv0, dn0);
+                win.template follow_axis<1, true>(win.oy, alive, ay, lane, a.edep, sXh, sYh, n_atomics, wide, w_slabs_wide, dv1, dn1);
+                win.template follow_axis<2, true>(win.oz, alive, az, lane, a.edep, sXh, sYh, n_atomics, wide, w_slabs_wide, dv2, dn2);
                 __builtin_amdgcn_wave_barrier();
                 inbox = alive && win.holds(ax, ay, az);
             } else {
                 // box A follows the lanes whose home it is
                 const bool memA = alive && !homeB;
-                win.template follow_axis<0, true>(win.ox, memA, ax, lane, a.edep, sXh, sYh, n_atomics, wide, w_slabs, dv0, dn0);
-                win.template follow_axis<1, true>(win.oy, memA, ay, lane, a.edep, sXh, sYh, n_atomics, wide, w_slabs, dv1, dn1);
-                win.template follow_axis<2, true>(win.oz, memA, az, lane, a.edep, sXh, sYh, n_atomics, wide, w_slabs, dv2, dn2);
+                win.template follow_axis<0, true>(win.ox, memA, ax, lane, a.edep, sXh, sYh, n_atomics, wide, w_slabs_wide, dv0, dn0);
+                win.template follow_axis<1, true>(win.oy, memA, ay, lane, a.edep, sXh, sYh, n_atomics, wide, w_slabs_wide, dv1, dn1);
+                win.template follow_axis<2, true>(win.oz, memA, az, lane, a.edep, sXh, sYh, n_atomics, wide, w_slabs_wide, dv2, dn2);
                 const bool inA = alive && win.holds(ax, ay, az);
                 bool inB = false;
                 if (b_active) {  // scalar branch
-                    ++w_bsteps;
+                    w_slabs_wide += 1u;
                     const bool memB = alive && homeB;
                     double tv = 0.0;
                     int tn = 0, tw = 0;
-                    winB.template follow_axis<0, false>(winB.ox, memB, ax, lane, a.edep, sXh, sYh, n_atomics, tw, w_slabs, tv, tn);
-                    winB.template follow_axis<1, false>(winB.oy, memB, ay, lane, a.edep, sXh, sYh, n_atomics, tw, w_slabs, tv, tn);
-                    winB.template follow_axis<2, false>(winB.oz, memB, az, lane, a.edep, sXh, sYh, n_atomics, tw, w_slabs, tv, tn);
+                    winB.template follow_axis<0, false>(winB.ox, memB, ax, lane, a.edep, sXh, sYh, n_atomics, tw, w_slabs_wide, tv, tn);
+                    winB.template follow_axis<1, false>(winB.oy, memB, ay, lane, a.edep, sXh, sYh, n_atomics, tw, w_slabs_wide, tv, tn);
+                    winB.template follow_axis<2, false>(winB.oz, memB, az, lane, a.edep, sXh, sYh, n_atomics, tw, w_slabs_wide, tv, tn);
                     inB = alive && winB.holds(ax, ay, az);
                 }
                 // lanes that fell out of A look for a home in B; an idle B is re-created around the first of them
@@ -722,8 +745,8 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
                 tile = useB ? MW::NDOUBLES : 0;
             }
             if (__builtin_amdgcn_ballot_w64(alive && !inbox) != 0ull) {
-                ++w_miss;
-                w_wide += wide ? 1 : 0;
+                w_steps_miss += 1u;
+                if (!TWOBOX && wide) w_slabs_wide += 1u;
             }
             // key: identifies the ordered set of 8 target nodes (own node + the three signs); lanes may
             // only be merged when they enumerate the corners in the same order, i.e. without FLIP
@@ -764,10 +787,18 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
             }
             __builtin_amdgcn_wave_barrier();
         }
-        // :351-356
-        if (alive && (s.uray <= s.ustop || s.px < a.xlo || s.px > a.xhi || s.py < a.ylo ||
-                      s.py > a.yhi || s.pz < a.zlo || s.pz > a.zhi))
-            alive = false;
+        // :351-356.  The six box bounds are compared only when some lane is within two cells of a
+        // face (wave-uniform ballot on the cell-unit position): a ray with 2 < f < n-3 on every axis
+        // is more than a cell and a half inside [min - d/2, max + d/2], far beyond any rounding.
+        // This keeps 12 scalar registers out of the hot loop (they are re-read from the argument
+        // block in the rare branch).
+        if (alive && s.uray <= s.ustop) alive = false;
+        const bool near_face = alive && !(fx > 2.0 && fx < a.fx_hi && fy > 2.0 && fy < a.fy_hi && fz > 2.0 && fz < a.fz_hi);
+        if (__builtin_amdgcn_ballot_w64(near_face) != 0ull) {
+            const double *b = a.bounds;  // {xlo, xhi, ylo, yhi, zlo, zhi}
+            if (alive && (s.px < b[0] || s.px > b[1] || s.py < b[2] || s.py > b[3] || s.pz < b[4] || s.pz > b[5]))
+                alive = false;
+        }
     }
 
     if (DEPOSIT == 2) {
@@ -790,11 +821,11 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
         atomicAdd(&a.counters[kCntRays], (unsigned long long)tot_rays);
         atomicAdd(&a.counters[kCntGlobalAtomics], (unsigned long long)tot_at);
         atomicAdd(&a.counters[kCntEvictions], (unsigned long long)tot_ev);
-        atomicAdd(&a.counters[kCntWaveSteps], (unsigned long long)w_steps);
+        atomicAdd(&a.counters[kCntWaveSteps], (unsigned long long)(w_steps_miss >> 16));
         if (DEPOSIT == 3) {
-            atomicAdd(&a.counters[kCntWaveStepsMiss], (unsigned long long)w_miss);
-            atomicAdd(&a.counters[kCntWaveStepsWide], (unsigned long long)(TWOBOX ? w_bsteps : w_wide));
-            atomicAdd(&a.counters[kCntSlabsRetired], (unsigned long long)w_slabs);
+            atomicAdd(&a.counters[kCntWaveStepsMiss], (unsigned long long)(w_steps_miss & 0xFFFFu));
+            atomicAdd(&a.counters[kCntWaveStepsWide], (unsigned long long)(w_slabs_wide & 0xFFFFu));
+            atomicAdd(&a.counters[kCntSlabsRetired], (unsigned long long)(w_slabs_wide >> 16));
         }
     }
 }
@@ -853,12 +884,12 @@ static void dispatch_trace(const TraceArgs &a, int variant, int wl, int rl, int 
 }
 
 hipError_t launch_trace(const TraceArgs &a, int variant, int window_log2, int copies_log2, int prereduce,
-                        bool corner_flip, bool two_boxes, hipStream_t stream)
+                        bool corner_flip, bool two_boxes, bool force_idx64, hipStream_t stream)
 {
     const long waves = (a.total_bundles - a.shard_index + a.shard_count - 1) / a.shard_count;
     if (waves <= 0) return hipSuccess;
     const dim3 grid((unsigned)waves);
-    const bool idx64 = (unsigned long long)a.nx * a.ny * a.nz * 8ull >= (1ull << 32);
+    const bool idx64 = force_idx64 || (unsigned long long)a.nx * a.ny * a.nz * 8ull >= (1ull << 32);
     // the pre-reduction key packs (flat haloed node index << 3 | signs) into 31 bits
     if ((long)(a.nx + 2) * (a.ny + 2) * (a.nz + 2) >= (1L << 28)) prereduce = 0;
     const bool flip = prereduce == 0 && corner_flip;

@@ -47,5 +47,22 @@ CBET_HD int relocate_closed(int c, double f, int n)
     return up ? upper : lower;
 }
 
+// Fast evaluation for an INTERIOR cell (1 <= c <= n-2, so neither neighbour needs a bound check):
+// only c+1 and c-1 are examined.  `ambiguous` is raised when the match lies within 2e-4 of the far
+// edge of its +-0.5001 band -- the only situation in which a second candidate (c for an upward
+// match, c-2 for a downward one) can match as well and relocate_closed() could differ.  The
+// margin (0.4998 vs the 0.4999 where the bands start to overlap) is 1e-4, ten orders above the
+// rounding of the subtractions.  Callers fall back to relocate_closed() when any lane is ambiguous
+// or sits on a face cell.
+CBET_HD int relocate_fast_interior(int c, double f, bool &ambiguous)
+{
+    const double half = 0.5001, safe = 0.4998;
+    const double fc = (double)c;
+    const double au = fabs((fc + 1.0) - f), ad = fabs((fc - 1.0) - f);
+    const bool up = au < half, dn = ad < half;
+    ambiguous = ambiguous || (up && au > safe) || (dn && ad > safe);
+    return up ? c + 1 : (dn ? c - 1 : c);
+}
+
 }  // namespace cbet
 #endif

@@ -54,7 +54,8 @@ class RayTracer:
 
     def launch(self, edep, shard_index=0, shard_count=1, beam_lo=0, beam_hi=None,
                kernel_variant=None, lds_window_log2=None, lds_copies_log2=None, lds_prereduce=None,
-               lds_corner_flip=None, lds_two_boxes=None, use_host_trig=True):
+               lds_corner_flip=None, lds_two_boxes=None, force_wide_index=None,
+               use_host_trig=True):
         """Enqueue one launch_ray_XYZ on torch's current stream, accumulating into `edep`."""
         if edep.dtype != torch.float64 or not edep.is_contiguous() or tuple(edep.shape) != self.grid_shape:
             raise ValueError("edep must be a contiguous float64 tensor of shape %s" % (self.grid_shape,))
@@ -73,6 +74,8 @@ class RayTracer:
             p.lds_corner_flip = lds_corner_flip
         if lds_two_boxes is not None:
             p.lds_two_boxes = lds_two_boxes
+        if force_wide_index is not None:
+            p.force_wide_index = force_wide_index
         d = self.derived
         stream = torch.cuda.current_stream(self.device).cuda_stream
         api.launch_ray_XYZ(0, d.nindices, self.d_te, self.d_r, self.d_ne, edep,

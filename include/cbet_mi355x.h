@@ -69,7 +69,9 @@ typedef struct cbet_params {
     int lds_corner_flip;         /* LDS_WINDOW: lane-dependent corner order (0/1; -1 = auto)   */
     int lds_two_boxes;           /* LDS_WINDOW: second window for lanes that leave the first   */
                                  /* (0/1; -1 = auto; implies 1 copy, no pre-reduction, flip)   */
-    int reserved[2];
+    int force_wide_index;        /* test hook: use the 64-bit node-table indexing path that grids  */
+                                 /* with 8*nx*ny*nz >= 2^32 bytes (n > 812) need, at any size      */
+    int reserved[1];
 } cbet_params;
 
 /* Quantities the reference derives in def.cuh / main.cu:156-161, evaluated in the same order. */

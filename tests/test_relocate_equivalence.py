@@ -17,7 +17,7 @@ int main() {
     std::uniform_real_distribution<double> wide(-3.0, 3.0), tiny(-3e-4, 3e-4), ulp(-40, 40);
     const double anchors[] = {-2.5001, -2.4999, -1.5001, -1.5, -1.4999, -0.5001, -0.5, -0.4999, 0.0,
                               0.4999, 0.5, 0.5001, 1.4999, 1.5, 1.5001, 2.4999, 2.5001};
-    long checked = 0, bad = 0;
+    long checked = 0, bad = 0, sure = 0;
     const int sizes[] = {3, 4, 5, 64, 100, 256};
     for (int n : sizes) {
         for (int c = 0; c < n; ++c) {
@@ -34,10 +34,15 @@ int main() {
                 int a = cbet::relocate_loop(c, f, n), b = cbet::relocate_closed(c, f, n);
                 ++checked;
                 if (a != b) { if (bad++ < 10) std::printf("MISMATCH n=%d c=%d f=%.17g loop=%d closed=%d\n", n, c, f, a, b); }
+                if (c >= 1 && c <= n - 2) {   // the kernel's fast path: must agree whenever it claims to be sure
+                    bool amb = false;
+                    int q = cbet::relocate_fast_interior(c, f, amb);
+                    if (!amb) { ++sure; if (q != a) { if (bad++ < 10) std::printf("FAST MISMATCH n=%d c=%d f=%.17g loop=%d fast=%d\n", n, c, f, a, q); } }
+                }
             }
         }
     }
-    std::printf("checked %ld bad %ld\n", checked, bad);
+    std::printf("checked %ld sure %ld bad %ld\n", checked, sure, bad);
     return bad != 0;
 }
 '''
@@ -52,3 +57,5 @@ def test_closed_form_equals_reference_loop(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
     assert "bad 0" in out.stdout
+    sure = int(out.stdout.split("sure")[1].split()[0])
+    assert sure > 50000             # the fast path is exercised, not always ambiguous
