@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--pre", type=int, default=-1, help="cbet_params.lds_prereduce (-1 = default)")
     ap.add_argument("--flip", type=int, default=-1, help="cbet_params.lds_corner_flip (-1 = default)")
     ap.add_argument("--twobox", type=int, default=-1, help="cbet_params.lds_two_boxes (-1 = default)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
+                    "rehearse the multi-rank flow on a 1-GPU box together with CBET_BENCH_DEVICE)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -78,10 +80,14 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    device_index = int(os.environ.get("CBET_BENCH_DEVICE", local_rank))  # rehearsal override only
+    torch.cuda.set_device(device_index)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     n = args.n
     r, ne, te = api.load_s83177()
@@ -136,6 +142,12 @@ def main():
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        check = edep.sum().reshape(1).clone()      # every rank must hold the same combined grid
+        lo, hi = check.clone(), check.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise SystemExit("ranks disagree on the all-reduced grid")
     steps_total = tot[0].item()                      # ray-steps over all ranks and all K steps
     elapsed_max = tmax[2].item()
     kernel_s_rank = tmax[3].item() / max(1, args.steps)   # slowest rank's average trace-kernel time
@@ -152,6 +164,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic (OMEGA-60 port table + s83177 ne/Te profile, deterministic)",
             "config": {"workload": "omega60_%dcube_s83177_absorption" % n, "grid": n, "beams": 60,
+                       "edep_sum": float(edep.sum().item()), "backend": args.backend if world > 1 else None,
                        "ray_steps_per_pass": steps_total / args.steps,
                        "rays_per_pass": 60 * int(d.nlive_rays), "kernel_variant": args.variant,
                        "sharding": "ray bundles interleaved over %d rank(s), all-reduce of the "
