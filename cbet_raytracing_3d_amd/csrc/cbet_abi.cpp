@@ -216,6 +216,7 @@ int cbet_params_default(cbet_params *p, int n)
     p->lds_prereduce = -1;
     p->lds_corner_flip = -1;
     p->lds_two_boxes = -1;
+    p->xcd_order = -1;
     return CBET_OK;
 }
 
@@ -532,6 +533,7 @@ int cbet_trace_nodes(int b, unsigned nindices, const double *ne3d, const double 
     a.total_bundles = (long)a.nbeams_local * a.bundles_per_beam;
     a.shard_index = p->shard_count > 1 ? p->shard_index : 0;
     a.shard_count = p->shard_count > 1 ? p->shard_count : 1;
+    a.xcd_chunk = p->xcd_order > 0 ? 1 : 0;  // launch_trace turns the flag into the chunk length
     a.ne3d = ne3d ? ne3d : ctx->ne3d;
     a.kap3d = kappa3d ? kappa3d : ctx->kap3d;
     a.beam_norm = beam_norm; a.bbeam_norm = bbeam_norm; a.pow_r = pow_r; a.phase_r = phase_r;

@@ -61,6 +61,7 @@ struct TraceArgs {
     int beam_lo, nbeams_local, bundles_per_beam;
     long total_bundles;
     int shard_index, shard_count;
+    int xcd_chunk;                          // > 0: XCD-aware workgroup -> work-item map (see k_trace)
     // tables
     const double *ne3d, *kap3d;
     const double *beam_norm, *bbeam_norm, *pow_r, *phase_r;

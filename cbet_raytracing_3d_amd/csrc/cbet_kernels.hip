@@ -486,8 +486,16 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
     __shared__ unsigned s_tag[NTAG];
     const int lane = threadIdx.x;
 
-    // which bundle: interleaved sharding over (beam, bundle) pairs
-    const long g = a.shard_index + (long)a.shard_count * blockIdx.x;
+    // which bundle: interleaved sharding over (beam, bundle) pairs.  Workgroups are dealt round-robin
+    // over the 8 XCDs (b and b+8 share an L2); with xcd_chunk > 0 workgroup b takes work item
+    // (b % 8) * xcd_chunk + b / 8, so that consecutive bundles -- neighbouring patches of one beam,
+    // which gather the same node-table lines -- run on the same XCD.  Placement only affects speed.
+    long w = blockIdx.x;
+    if (a.xcd_chunk > 0) {
+        w = (long)(blockIdx.x & 7) * a.xcd_chunk + (blockIdx.x >> 3);
+        if ((blockIdx.x >> 3) >= a.xcd_chunk) return;
+    }
+    const long g = a.shard_index + (long)a.shard_count * w;
     if (g >= a.total_bundles) return;  // wave-uniform
     const int beam = a.beam_lo + (int)(g / a.bundles_per_beam);
     const int li = (int)(g % a.bundles_per_beam) * kWave + lane;
@@ -888,13 +896,16 @@ hipError_t launch_trace(const TraceArgs &a, int variant, int window_log2, int co
 {
     const long waves = (a.total_bundles - a.shard_index + a.shard_count - 1) / a.shard_count;
     if (waves <= 0) return hipSuccess;
-    const dim3 grid((unsigned)waves);
+    const long chunk = a.xcd_chunk > 0 ? (waves + 7) / 8 : 0;
+    TraceArgs b = a;
+    b.xcd_chunk = (int)chunk;
+    const dim3 grid((unsigned)(chunk > 0 ? chunk * 8 : waves));
     const bool idx64 = force_idx64 || (unsigned long long)a.nx * a.ny * a.nz * 8ull >= (1ull << 32);
     // the pre-reduction key packs (flat haloed node index << 3 | signs) into 31 bits
     if ((long)(a.nx + 2) * (a.ny + 2) * (a.nz + 2) >= (1L << 28)) prereduce = 0;
     const bool flip = prereduce == 0 && corner_flip;
-    if (idx64) dispatch_trace<true>(a, variant, window_log2, copies_log2, prereduce, flip, two_boxes, grid, stream);
-    else dispatch_trace<false>(a, variant, window_log2, copies_log2, prereduce, flip, two_boxes, grid, stream);
+    if (idx64) dispatch_trace<true>(b, variant, window_log2, copies_log2, prereduce, flip, two_boxes, grid, stream);
+    else dispatch_trace<false>(b, variant, window_log2, copies_log2, prereduce, flip, two_boxes, grid, stream);
     return hipGetLastError();
 }
 

@@ -54,7 +54,7 @@ class RayTracer:
 
     def launch(self, edep, shard_index=0, shard_count=1, beam_lo=0, beam_hi=None,
                kernel_variant=None, lds_window_log2=None, lds_copies_log2=None, lds_prereduce=None,
-               lds_corner_flip=None, lds_two_boxes=None, force_wide_index=None,
+               lds_corner_flip=None, lds_two_boxes=None, force_wide_index=None, xcd_order=None,
                use_host_trig=True):
         """Enqueue one launch_ray_XYZ on torch's current stream, accumulating into `edep`."""
         if edep.dtype != torch.float64 or not edep.is_contiguous() or tuple(edep.shape) != self.grid_shape:
@@ -76,6 +76,8 @@ class RayTracer:
             p.lds_two_boxes = lds_two_boxes
         if force_wide_index is not None:
             p.force_wide_index = force_wide_index
+        if xcd_order is not None:
+            p.xcd_order = xcd_order
         d = self.derived
         stream = torch.cuda.current_stream(self.device).cuda_stream
         api.launch_ray_XYZ(0, d.nindices, self.d_te, self.d_r, self.d_ne, edep,

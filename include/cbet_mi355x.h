@@ -71,7 +71,8 @@ typedef struct cbet_params {
                                  /* (0/1; -1 = auto; implies 1 copy, no pre-reduction, flip)   */
     int force_wide_index;        /* test hook: use the 64-bit node-table indexing path that grids  */
                                  /* with 8*nx*ny*nz >= 2^32 bytes (n > 812) need, at any size      */
-    int reserved[1];
+    int xcd_order;               /* workgroup order: 1 = consecutive bundles on one XCD, 0 = plain, */
+                                 /* -1 = auto                                                       */
 } cbet_params;
 
 /* Quantities the reference derives in def.cuh / main.cu:156-161, evaluated in the same order. */
