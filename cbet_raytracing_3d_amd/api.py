@@ -86,7 +86,7 @@ EXPORTS = [
     "cbet_safeGPUAlloc", "cbet_moveToAndFromGPU", "cbet_gpuFree",
     "cbet_context_create", "cbet_context_destroy", "cbet_context_counters", "cbet_context_tables",
     "cbet_launch_ray_XYZ", "cbet_tabulate_plasma", "cbet_trace_nodes", "cbet_ray_tracing",
-    "cbet_write_text", "cbet_edep_average",
+    "cbet_write_text", "cbet_edep_average", "cbet_debug_bounds_violations",
 ]
 
 _lib = None
@@ -126,6 +126,7 @@ def lib():
                                    C.c_double, C.c_double, C.c_double, C.POINTER(Params), vp, vp]
     L.cbet_ray_tracing.argtypes = [dp, dp, dp, dp, C.POINTER(Params), dp, ip, C.c_int, dp,
                                    C.POINTER(Counters)]
+    L.cbet_debug_bounds_violations.argtypes = [C.POINTER(C.c_ulonglong), C.c_int, vp]
     L.cbet_write_text.argtypes = [dp, C.c_int, C.c_int, C.c_int, C.c_char_p]
     L.cbet_write_text.restype = C.c_longlong
     L.cbet_edep_average.argtypes = [dp, dp, C.c_int, C.c_int, C.c_int]
@@ -355,3 +356,10 @@ def edep_average(edep):
     out = np.zeros((nx, ny, nz))
     _check(lib().cbet_edep_average(_dptr(e), _dptr(out), nx, ny, nz))
     return out
+
+
+def debug_bounds_violations(reset=True, stream=None):
+    """Bounds-audit builds only: out-of-range accesses the kernels attempted since the last reset."""
+    n = C.c_ulonglong()
+    _check(lib().cbet_debug_bounds_violations(C.byref(n), 1 if reset else 0, _addr(stream)))
+    return int(n.value)

@@ -428,6 +428,15 @@ int cbet_context_counters(cbet_context *ctx, void *stream, cbet_counters *out, i
     return CBET_OK;
 }
 
+int cbet_debug_bounds_violations(unsigned long long *out, int reset, void *stream)
+{
+    if (!out) return fail(CBET_EINVAL, "out is NULL");
+    hipError_t e = audit_violations(out, reset != 0, (hipStream_t)stream);
+    if (e == hipErrorNotSupported) return fail(CBET_EINVAL, "not a bounds-audit build (compile with -DCBET_DEBUG_BOUNDS)");
+    if (e != hipSuccess) return fail(CBET_EHIP, "audit_violations: %s", hipGetErrorString(e));
+    return CBET_OK;
+}
+
 int cbet_context_tables(cbet_context *ctx, double **ne3d, double **kappa3d)
 {
     if (!ctx) return fail(CBET_EINVAL, "NULL context");

@@ -70,6 +70,7 @@ struct TraceArgs {
 };
 
 hipError_t launch_tabulate(const TabulateArgs &a, hipStream_t stream);
+hipError_t audit_violations(unsigned long long *out, bool reset, hipStream_t stream);
 hipError_t launch_trace(const TraceArgs &a, int variant, int window_log2, int copies_log2, int prereduce,
                         bool corner_flip, bool two_boxes, bool force_idx64, hipStream_t stream);
 

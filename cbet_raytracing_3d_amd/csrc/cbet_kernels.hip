@@ -175,8 +175,23 @@ __device__ __forceinline__ bool launch_ray(const TraceArgs &a, int beam, int pre
     return true;
 }
 
+#ifdef CBET_DEBUG_BOUNDS
+// Bounds-audited build (tests/test_gpu_bounds_audit.py): every grid atomic, node-table gather and
+// LDS accumulate is range-checked; a violation is counted and the access skipped.  Never shipped.
+__device__ const double *g_audit_edep_lo, *g_audit_edep_hi;
+__device__ unsigned long long g_audit_nodes;
+__device__ unsigned long long g_audit_violations;
+__device__ __forceinline__ bool audit_fail() { atomicAdd(&g_audit_violations, 1ull); return true; }
+#define CBET_AUDIT(cond) ((cond) || !audit_fail())
+#else
+#define CBET_AUDIT(cond) true
+#endif
+
 __device__ __forceinline__ void global_add(double *p, double v)
 {
+#ifdef CBET_DEBUG_BOUNDS
+    if (!(p >= g_audit_edep_lo && p < g_audit_edep_hi)) { audit_fail(); return; }
+#endif
     // native global_atomic_add_f64, no CAS loop (checked in the ISA)
     unsafeAtomicAdd(p, v);
 }
@@ -222,7 +237,8 @@ struct LdsWindow {
     }
     __device__ __forceinline__ void add(unsigned s, double w)
     {
-        __hip_atomic_fetch_add(&val[s], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (CBET_AUDIT(s < (unsigned)NSLOT))
+            __hip_atomic_fetch_add(&val[s], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     // Write every live slot back (wave end).
     __device__ __forceinline__ int flush(int lane, double *edep)
@@ -361,6 +377,7 @@ struct MovingWindow {
             if (AX == 0) { i = coord; j = absolute(oy, r0); k = absolute(oz, r1); slot = addr(fixed, r0, r1); }
             else if (AX == 1) { i = absolute(ox, r0); j = coord; k = absolute(oz, r1); slot = addr(r0, fixed, r1); }
             else { i = absolute(ox, r0); j = absolute(oy, r1); k = coord; slot = addr(r0, r1, fixed); }
+            if (!CBET_AUDIT((unsigned)((R - 1) * CS + slot) < (unsigned)NDOUBLES)) continue;
             double v = val[slot];
 #pragma unroll
             for (int c = 1; c < R; ++c) v += val[c * CS + slot];
@@ -418,9 +435,11 @@ struct MovingWindow {
         int dn = 0;
         for (int t = 0; t < W; ++t) retire<0, false>(ox + t, lane, edep, sXh, sYh, n_at, dv, dn);
     }
+    int limit;  // doubles addressable from val (both boxes' tiles when there are two)
     __device__ __forceinline__ void add(int slot, double w)
     {
-        __hip_atomic_fetch_add(&val[slot], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (CBET_AUDIT((unsigned)slot < (unsigned)limit))
+            __hip_atomic_fetch_add(&val[slot], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 };
 
@@ -461,6 +480,9 @@ __device__ __forceinline__ void merge_level(int lane, int &key, double (&w)[8])
 template <bool IDX64>
 __device__ __forceinline__ double node_load(const double *base, unsigned idx)
 {
+#ifdef CBET_DEBUG_BOUNDS
+    if (!(idx < g_audit_nodes)) { audit_fail(); return 0.0; }
+#endif
     if (IDX64) return base[idx];
     return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + (idx * 8u));
 }
@@ -516,12 +538,13 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
     unsigned w_slabs_wide = 0;   // slabs retired << 16 | wave-steps "too wide" (two boxes: box B live)
 
     LdsWindow<WL> tagged{s_val, s_tag};
-    MovingWindow<WL, RL> win{s_val, 0, 0, 0};
+    MovingWindow<WL, RL> win{s_val, 0, 0, 0, NSLOT};
     // Second box (TWOBOX): after the turning point a bundle fans out to 6-11 cells (scripts/
     // bundle_spread.py), wider than one 8-cell box.  Lanes that fall out of box A are adopted by
     // box B (sticky per-lane home bit); B is created around the first such lane and flushed when
     // its last lane leaves or dies.
-    MovingWindow<WL, RL> winB{s_val + (TWOBOX ? MovingWindow<WL, RL>::NDOUBLES : 0), 0, 0, 0};
+    MovingWindow<WL, RL> winB{s_val + (TWOBOX ? MovingWindow<WL, RL>::NDOUBLES : 0), 0, 0, 0,
+                              MovingWindow<WL, RL>::NDOUBLES};
     bool homeB = false;     // per lane
     bool b_active = false;  // wave-uniform
 
@@ -891,11 +914,37 @@ static void dispatch_trace(const TraceArgs &a, int variant, int wl, int rl, int 
     }
 }
 
+hipError_t audit_violations(unsigned long long *out, bool reset, hipStream_t stream)
+{
+#ifdef CBET_DEBUG_BOUNDS
+    hipError_t e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_audit_violations), sizeof *out);
+    if (e == hipSuccess && reset) {
+        const unsigned long long zero = 0;
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_audit_violations), &zero, sizeof zero);
+    }
+    return e;
+#else
+    (void)out; (void)reset; (void)stream;
+    return hipErrorNotSupported;
+#endif
+}
+
 hipError_t launch_trace(const TraceArgs &a, int variant, int window_log2, int copies_log2, int prereduce,
                         bool corner_flip, bool two_boxes, bool force_idx64, hipStream_t stream)
 {
     const long waves = (a.total_bundles - a.shard_index + a.shard_count - 1) / a.shard_count;
     if (waves <= 0) return hipSuccess;
+#ifdef CBET_DEBUG_BOUNDS
+    {
+        const double *lo = a.edep, *hi = a.edep + (long)(a.nx + 2) * (a.ny + 2) * (a.nz + 2);
+        const unsigned long long nodes = (unsigned long long)a.nx * a.ny * a.nz;
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_audit_edep_lo), &lo, sizeof lo, 0, hipMemcpyHostToDevice, stream);
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_audit_edep_hi), &hi, sizeof hi, 0, hipMemcpyHostToDevice, stream);
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_audit_nodes), &nodes, sizeof nodes, 0, hipMemcpyHostToDevice, stream);
+    }
+#endif
     const long chunk = a.xcd_chunk > 0 ? (waves + 7) / 8 : 0;
     TraceArgs b = a;
     b.xcd_chunk = (int)chunk;

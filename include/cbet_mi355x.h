@@ -165,6 +165,13 @@ int cbet_context_counters(cbet_context *ctx, void *stream, cbet_counters *out, i
 /* Device pointers of the node tables (for tests / the 3-D plasma entry below). */
 int cbet_context_tables(cbet_context *ctx, double **ne3d, double **kappa3d);
 
+/*
+ * Bounds-audit builds only (-DCBET_DEBUG_BOUNDS; tests/test_gpu_bounds_audit.py): number of
+ * out-of-range grid atomics / node-table gathers / LDS accumulates the kernels attempted (and
+ * skipped) on the current device since the last reset.  Regular builds return CBET_EINVAL.
+ */
+int cbet_debug_bounds_violations(unsigned long long *out, int reset, void *stream);
+
 /* ---- the hot path ---------------------------------------------------------------------------- */
 /*
  * launch_ray_XYZ (launch_ray_XZ.cu:117-121; launch site main.cu:171-174).  Same thirteen

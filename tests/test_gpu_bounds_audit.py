@@ -1,0 +1,77 @@
+"""Edge-case geometries through a bounds-audited build of the library.
+
+The audit build (-DCBET_DEBUG_BOUNDS, compiled here with hipcc into a temp dir) range-checks every
+grid atomic, node-table gather and LDS accumulate in the kernels, counting and skipping violations.
+Tiny, ragged and face-hugging configurations run through it in a subprocess (the library path is
+fixed at import) and must (a) attempt no out-of-range access and (b) match the oracle.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+WORKER = r'''
+import json, os, sys
+import numpy as np, torch
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+from conftest import load_inputs, parity_err
+from cbet_raytracing_3d_amd import api
+from cbet_raytracing_3d_amd.tracer import RayTracer
+from oracle import cbet_oracle as O
+bn, r, ne, te = load_inputs()
+cases = [  # (nx, ny, nz, rays_per_zone, beams, absorption)
+    (3, 3, 3, 4, [0, 30], 1), (4, 5, 3, 2, [3, 41], 1), (8, 8, 8, 1, [0, 1, 2], 1), (9, 7, 13, 5, [10, 50], 1),
+    (16, 16, 16, 4, [0, 15, 30, 45], 0), (33, 20, 27, 3, [7, 22, 37, 52], 1), (64, 64, 64, 4, list(range(0, 60, 6)), 1),
+]
+out = []
+for nx, ny, nz, rpz, beams, absorb in cases:
+    for variant in (1, 2, 3):
+        p = api.default_params(nx, nbeams=len(beams), rays_per_zone=rpz, absorption=absorb, kernel_variant=variant)
+        p.ny, p.nz = ny, nz
+        tr = RayTracer(p, r, ne, te, beam_norm=bn[beams])
+        e = tr.new_grid(); tr.counters(reset=True)
+        tr.launch(e)
+        c = tr.counters(reset=True)
+        viol = api.debug_bounds_violations(reset=True)
+        cfg = O.default_config(nx, nbeams=len(beams), rays_per_zone=rpz, absorption=absorb)
+        cfg.ny, cfg.nz = ny, nz
+        oe, osteps = O.trace(cfg, bn[beams].copy(), r, ne, te, nthreads=8)
+        err = parity_err(e.cpu().numpy(), oe) if np.abs(oe).max() > 0 else float(np.abs(e.cpu().numpy()).max())
+        out.append(dict(case=[nx, ny, nz, rpz, len(beams), absorb], variant=variant, violations=viol,
+                        steps=int(c.ray_steps), osteps=int(osteps), err=err))
+        tr.close()
+print("RESULT " + json.dumps(out))
+'''
+
+
+def test_edge_geometries_in_bounds_audited_build(tmp_path):
+    csrc = os.path.join(ROOT, "cbet_raytracing_3d_amd", "csrc")
+    lib = str(tmp_path / "libcbet_audit.so")
+    srcs = [os.path.join(csrc, f) for f in ("cbet_kernels.hip", "cbet_abi.cpp", "cbet_host.cpp", "cbet_output.cpp")]
+    subprocess.check_call(["hipcc", "-O2", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC",
+                           "-shared", "-DCBET_DEBUG_BOUNDS", "-I", os.path.join(ROOT, "include"), "-I", csrc,
+                           "-o", lib] + srcs + ["-lrccl"])
+    env = dict(os.environ, CBET_LIB_PATH=lib)
+    run = subprocess.run([sys.executable, "-c", WORKER % {"root": ROOT}], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    line = [l for l in run.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    results = json.loads(line[len("RESULT "):])
+    assert len(results) == 21
+    for res in results:
+        assert res["violations"] == 0, res
+        assert res["steps"] == res["osteps"], res
+        assert res["err"] < 1e-9, res
+
+
+def test_regular_build_reports_no_audit(tmp_path):
+    from cbet_raytracing_3d_amd import api
+    with pytest.raises(api.CbetError) as ei:
+        api.debug_bounds_violations()
+    assert ei.value.code == api.EINVAL
