@@ -140,10 +140,25 @@ static void build_live_list(const cbet_params *p, const cbet_derived *d, int nin
     const int rpz = p->rays_per_zone, rpz2 = rpz * rpz;
     const int zx = d->zones_spanned;
     const int px = (d->nrays_x + 7) / 8, py = (d->nrays_y + 7) / 8;
-    std::vector<std::pair<unsigned, int>> order;
+    // Visit order of the patches.  patch_order 0: Morton curve (neighbouring patches consecutive).
+    // patch_order 1 (default): longest rays first -- rays launched far from the beam axis cross the
+    // whole box (~4x the steps of the central rays, which are absorbed early), and a launch is only
+    // a few rounds of the chip once the work is sharded 8 ways, so dispatching the long bundles
+    // first and the short ones last trims the tail.  Ties (and order 0) fall back to Morton.
+    std::vector<std::pair<unsigned long long, int>> order;
     order.reserve((size_t)px * py);
     for (int y = 0; y < py; ++y)
-        for (int x = 0; x < px; ++x) order.emplace_back(morton2(x, y), y * px + x);
+        for (int x = 0; x < px; ++x) {
+            unsigned long long key = morton2(x, y);
+            if (p->patch_order != 0) {
+                const int cx = std::min(d->nrays_x - 1, x * 8 + 4), cy = std::min(d->nrays_y - 1, y * 8 + 4);
+                const double r2 = xl[cx] * xl[cx] + yl[cy] * yl[cy];
+                const double rmax2 = 2.0 * kBeamMax * kBeamMax * 1.1;
+                const unsigned long long ring = (unsigned long long)((1.0 - std::min(1.0, r2 / rmax2)) * 4095.0);  // 0 = outermost
+                key |= ring << 32;
+            }
+            order.emplace_back(key, y * px + x);
+        }
     std::sort(order.begin(), order.end());
     slots.clear();
     ntraced = 0;
@@ -217,6 +232,7 @@ int cbet_params_default(cbet_params *p, int n)
     p->lds_corner_flip = -1;
     p->lds_two_boxes = -1;
     p->xcd_order = -1;
+    p->patch_order = 1;
     return CBET_OK;
 }
 
@@ -453,7 +469,7 @@ static int check_geometry(const cbet_context *ctx, const cbet_params *p)
         p->ymin != q.ymin || p->ymax != q.ymax || p->zmin != q.zmin || p->zmax != q.zmax ||
         p->rays_per_zone != q.rays_per_zone || p->nbeams != q.nbeams || p->nprofile != q.nprofile ||
         p->max_threads != q.max_threads || p->threads_per_block != q.threads_per_block ||
-        p->courant_mult != q.courant_mult)
+        p->courant_mult != q.courant_mult || p->patch_order != q.patch_order)
         return fail(CBET_EINVAL, "launch parameters do not match the geometry the context was created for");
     return CBET_OK;
 }

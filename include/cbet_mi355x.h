@@ -73,6 +73,9 @@ typedef struct cbet_params {
                                  /* with 8*nx*ny*nz >= 2^32 bytes (n > 812) need, at any size      */
     int xcd_order;               /* workgroup order: 1 = consecutive bundles on one XCD, 0 = plain, */
                                  /* -1 = auto                                                       */
+    int patch_order;             /* launch-list order of the 8x8-ray patches of a beam: 1 = longest  */
+                                 /* rays (largest launch radius) first, 0 = Morton curve.  Part of   */
+                                 /* the geometry a context is created for.                           */
 } cbet_params;
 
 /* Quantities the reference derives in def.cuh / main.cu:156-161, evaluated in the same order. */
