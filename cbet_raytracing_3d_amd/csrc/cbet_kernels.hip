@@ -11,14 +11,17 @@
 //                     without the trailing *uray).  The reference re-interpolates the profile eight
 //                     times per ray-step (8 bisections + 9 sqrt + 9 div); here a ray-step is seven
 //                     8-byte gathers and ~60 flops, no sqrt/div.
-//   * k_trace       : one wavefront (64 lanes) = one ray bundle = one 8x8-ray patch of the beam
-//                     cross section (patches in Morton order, dead patches dropped, culled rays
-//                     are idle lanes), so a wave's gathers and deposits fall in a few
-//                     neighbouring cells.
-//       DEPOSIT = GLOBAL : 8 global_atomic_add_f64 per ray-step (the reference's scheme).
-//       DEPOSIT = LDS    : deposits are combined in a wave-private, toroidally indexed LDS window
-//                     (W^3 fp64 accumulators + tags); a slot is written back with one global atomic
-//                     when the bundle has moved on and another node claims it, and at wave end.
+//   * k_trace       : one wavefront (64 lanes, one workgroup) = one ray bundle = one 8x8-ray patch
+//                     of the beam cross section (the host orders the patches, drops dead ones and
+//                     marks culled rays as holes), so a wave's gathers and deposits fall in a few
+//                     neighbouring cells.  The step loop is software-pipelined (next step's gathers
+//                     are issued right after relocation).  Three deposit schemes, template DEPOSIT:
+//       1  GLOBAL : 8 global_atomic_add_f64 per ray-step (the reference's scheme, kept as baseline).
+//       2  TAGGED : wave-private toroidal LDS tile with node tags; slots are claimed by LDS CAS and
+//                   written back with one global atomic when another node claims them.
+//       3  WINDOW : (default) wave-private dense LDS tiles without tags whose origins follow the
+//                   bundle; a slab leaving a box is flushed with one global atomic per node.  See
+//                   MovingWindow and DESIGN.md 4.2 for the measurements behind each choice.
 #include <hip/hip_runtime.h>
 
 #include "cbet_device.h"
