@@ -147,8 +147,8 @@ def main():
         lo, hi = check.clone(), check.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        if not torch.equal(lo, hi):
-            raise SystemExit("ranks disagree on the all-reduced grid")
+        if not bool(((hi - lo).abs() <= 1e-9 * hi.abs()).all()):   # bit-identity is not guaranteed by every algorithm
+            raise SystemExit("ranks disagree on the all-reduced grid: %r vs %r" % (lo.item(), hi.item()))
     steps_total = tot[0].item()                      # ray-steps over all ranks and all K steps
     elapsed_max = tmax[2].item()
     kernel_s_rank = tmax[3].item() / max(1, args.steps)   # slowest rank's average trace-kernel time
