@@ -510,6 +510,10 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
     __shared__ double s_val[NSLOT];
     __shared__ unsigned s_tag[NTAG];
     const int lane = threadIdx.x;
+#ifdef CBET_EXPERIMENT_EXTRA_LDS  // occupancy-sensitivity experiment builds only (scripts/experiment_occupancy.sh)
+    __shared__ double s_pad[CBET_EXPERIMENT_EXTRA_LDS / 8];
+    if (a.nt < 0) s_pad[lane] = 1.0;  // keep the allocation alive
+#endif
 
     // which bundle: interleaved sharding over (beam, bundle) pairs.  Workgroups are dealt round-robin
     // over the 8 XCDs (b and b+8 share an L2); with xcd_chunk > 0 workgroup b takes work item
