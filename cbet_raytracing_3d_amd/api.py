@@ -98,6 +98,13 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process.  torch ships its own libamdhip64 / libhsa-runtime64 / librccl;
+    # if libcbet_mi355x.so were loaded first it would pull in /opt/rocm's copies and the process would
+    # hold two runtimes (the second to touch the device then fails, and streams / events of one mean
+    # nothing to the other).  Importing torch first makes the loader resolve this library's HIP and
+    # RCCL dependencies to the copies torch has already mapped (checked with scripts/which_hip.py),
+    # so torch.cuda streams, events and tensors are valid arguments to every call below.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "%s is missing: build it with `python -m cbet_raytracing_3d_amd.build` "

@@ -58,7 +58,8 @@ static int validate(const cbet_params *p)
     if (p->nbeams < 1) return fail(CBET_EINVAL, "nbeams < 1");
     if (p->rays_per_zone < 1 || p->rays_per_zone > 64) return fail(CBET_EINVAL, "rays_per_zone out of range");
     if (!(p->courant_mult > 0)) return fail(CBET_EINVAL, "courant_mult <= 0");
-    if (p->nprofile < 2 || p->nprofile > 4096) return fail(CBET_EINVAL, "nprofile out of range [2,4096]");
+    // k_tabulate stages 3 * nprofile doubles in dynamic LDS; 2048 rows = 48 KB, inside the default limit
+    if (p->nprofile < 2 || p->nprofile > 2048) return fail(CBET_EINVAL, "nprofile out of range [2,2048]");
     if (p->max_threads < 1 || p->threads_per_block < 1) return fail(CBET_EINVAL, "bad launch-shape rule");
     if (p->shard_count > 1 && (p->shard_index < 0 || p->shard_index >= p->shard_count))
         return fail(CBET_EINVAL, "shard_index outside [0, shard_count)");

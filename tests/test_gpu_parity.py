@@ -407,3 +407,29 @@ def test_stress_512_properties(api, inputs, torch_cuda):
     assert parity_err(e3, e2) < 1e-10
     print("512^3: %d ray-steps, %.3f global atomics/step" % (c3.ray_steps, c3.global_atomics / c3.ray_steps))
     tr.close()
+
+
+@pytest.mark.parametrize("nprofile", [2, 64, 2048])
+def test_analytic_profile_of_other_lengths(api, oracle, inputs, torch_cuda, nprofile):
+    """Profiles need not have 443 rows (def.cuh:33 is a run-time field here).  SURVEY 8(d)'s synthetic
+    stand-in ne(r) = ncrit * exp(-(r - 0.035)/0.01), Te rising with r; 2 rows = a linear profile."""
+    bn = inputs[0]
+    from cbet_raytracing_3d_amd.tracer import RayTracer
+    p = api.default_params(40, nbeams=5, nprofile=nprofile)
+    d = api.derive(p)
+    r = np.linspace(0.0, 0.3, nprofile)
+    if nprofile == 2:       # two rows can only be a straight line: keep it under-critical everywhere
+        ne = d.ncrit * np.array([0.9, 0.0])
+    else:
+        ne = d.ncrit * np.exp(-(r - 0.035) / 0.01)
+    te = 500.0 + 6000.0 * r
+    beams = [2, 14, 33, 47, 58]
+    tr = RayTracer(p, r, ne, te, beam_norm=bn[beams])
+    e, c = run(tr, torch_cuda)
+    cfg = oracle.default_config(40, nbeams=5, nprofile=nprofile)
+    oe, osteps = oracle.trace(cfg, bn[beams].copy(), r, ne, te, nthreads=NCPU)
+    assert c.ray_steps == osteps and osteps > 0
+    assert parity_err(e, oe) < PARITY_TOL
+    tr.close()
+    with pytest.raises(api.CbetError):
+        api.derive(api.default_params(40, nprofile=2049))
