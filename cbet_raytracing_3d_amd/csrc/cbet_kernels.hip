@@ -60,6 +60,26 @@ __device__ __forceinline__ double interp_table(const double *y, const double *x,
     return y[mid] + (y[mid + 1] - y[mid]) / (x[mid + 1] - x[mid]) * (xp - x[mid]);
 }
 
+// Two tables over ONE abscissa (ne and Te share r_data, launch_ray_XZ.cu:297-298): the bisection
+// depends only on (x, xp), so it is done once and both values are interpolated from the same
+// segment -- bit for bit what two interp_table() calls return.
+__device__ __forceinline__ void interp_table2(const double *y1, const double *y2, const double *x, const double xp,
+                                              int n, double &o1, double &o2)
+{
+    const bool ascending = x[0] <= x[n - 1];
+    if (ascending ? (xp <= x[0]) : (xp >= x[0])) { o1 = y1[0]; o2 = y2[0]; return; }
+    if (ascending ? (xp >= x[n - 1]) : (xp <= x[n - 1])) { o1 = y1[n - 1]; o2 = y2[n - 1]; return; }
+    unsigned lo = 0, hi = n - 1, mid = (lo + hi) >> 1;
+    while (lo < hi - 1) {
+        const bool go_low = ascending ? (x[mid] >= xp) : !(x[mid] <= xp);  // :31 / :52 (as written there)
+        if (go_low) hi = mid; else lo = mid;
+        mid = (lo + hi) >> 1;
+    }
+    const double dx = x[mid + 1] - x[mid], t = xp - x[mid];
+    o1 = y1[mid] + (y1[mid + 1] - y1[mid]) / dx * t;
+    o2 = y2[mid] + (y2[mid + 1] - y2[mid]) / dx * t;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Node tables.  One thread per node, grid-stride; the 3 x nprofile profile is staged in LDS
 // (the one thing kept from the reference's layout, launch_ray_XZ.cu:136-150).
@@ -84,8 +104,8 @@ __global__ void __launch_bounds__(256) k_tabulate(const TabulateArgs a)
         // launch_ray_XZ.cu:296 -- node radius, squares summed x,y,z
         const double xc = i * a.dx + a.xmin, yc = j * a.dy + a.ymin, zc = k * a.dz + a.zmin;
         const double rho = sqrt(xc * xc + yc * yc + zc * zc);
-        const double ed = interp_table(s_ne, s_r, rho, a.nprofile);     // :297
-        const double etemp = interp_table(s_te, s_r, rho, a.nprofile);  // :298
+        double ed, etemp;                                               // :297-298
+        interp_table2(s_ne, s_te, s_r, rho, a.nprofile, ed, etemp);
         const double eta = 5.2e-5 * 10.0 / (etemp * sqrt(etemp));       // :299
         const double nuei = (1e6 * ed * (kEc * kEc) / kMe) * eta;       // :300
         a.ne3d[idx] = ed;
