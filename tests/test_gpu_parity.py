@@ -433,3 +433,20 @@ def test_analytic_profile_of_other_lengths(api, oracle, inputs, torch_cuda, npro
     tr.close()
     with pytest.raises(api.CbetError):
         api.derive(api.default_params(40, nprofile=2049))
+
+
+def test_orchestrator_fails_cleanly_without_enough_devices(api, inputs, torch_cuda):
+    """cbet_ray_tracing on more devices than exist: a status, not a crash (the reference ignores
+    every return value, main.cu:136-151); the next valid call still works."""
+    bn, r, ne, te = inputs
+    ndev = torch_cuda.cuda.device_count()
+    p = api.default_params(24, nbeams=2)
+    edep = np.zeros((26, 26, 26))
+    with pytest.raises(api.CbetError) as ei:
+        api.ray_tracing(te, r, ne, edep, p, beam_norm=bn[:2], gpus=list(range(ndev + 1)))
+    assert ei.value.code in (api.ENODEVICE, api.EHIP)
+    assert float(np.abs(edep).sum()) == 0.0              # nothing was added on failure
+    with pytest.raises(api.CbetError):
+        api.ray_tracing(te, r, ne, edep, p, beam_norm=bn[:2], gpus=[-1])
+    timers, cnt = api.ray_tracing(te, r, ne, edep, p, beam_norm=bn[:2], gpus=[0])
+    assert cnt.ray_steps > 0 and edep.sum() > 0
