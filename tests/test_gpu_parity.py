@@ -450,3 +450,20 @@ def test_orchestrator_fails_cleanly_without_enough_devices(api, inputs, torch_cu
         api.ray_tracing(te, r, ne, edep, p, beam_norm=bn[:2], gpus=[-1])
     timers, cnt = api.ray_tracing(te, r, ne, edep, p, beam_norm=bn[:2], gpus=[0])
     assert cnt.ray_steps > 0 and edep.sum() > 0
+
+
+def test_native_wide_index_grid_832(api, inputs, torch_cuda):
+    """n = 832: each node table is 4.6 GB, so byte offsets exceed 32 bits and the kernels switch to
+    64-bit indexing on their own (the maximum the 32-bit node tags allow is n = 1288).  No oracle at
+    this size in test time: the two LDS schemes must agree cell by cell and count the same steps."""
+    tr = make_tracer(api, inputs, 832, beams=[0, 21, 40, 59])
+    d = tr.derived
+    assert 8 * tr.params.nx * tr.params.ny * tr.params.nz >= 2 ** 32
+    e3, c3 = run(tr, torch_cuda, kernel_variant=3)
+    assert c3.rays_traced == 4 * d.nlive_rays and c3.ray_steps > 3e9
+    s3, m3, z3 = float(e3.sum()), float(e3.max()), e3[417, 417, 417]
+    del e3
+    e2, c2 = run(tr, torch_cuda, kernel_variant=2)
+    assert c2.ray_steps == c3.ray_steps
+    assert abs(float(e2.sum()) / s3 - 1) < 1e-12 and abs(float(e2.max()) / m3 - 1) < 1e-12 and z3 == 0.0
+    tr.close()
