@@ -467,3 +467,22 @@ def test_native_wide_index_grid_832(api, inputs, torch_cuda):
     assert c2.ray_steps == c3.ray_steps
     assert abs(float(e2.sum()) / s3 - 1) < 1e-12 and abs(float(e2.max()) / m3 - 1) < 1e-12 and z3 == 0.0
     tr.close()
+
+
+def test_full_grid_parity_128(api, oracle, inputs, torch_cuda):
+    """60 beams, s83177, 128^3: all 130^3 cells against the oracle (the largest size at which the
+    oracle runs in test time), default kernel; also pins sharded (1/8) launches cell by cell."""
+    bn, r, ne, te = inputs
+    tr = make_tracer(api, inputs, 128)
+    e, c = run(tr, torch_cuda)
+    oe, osteps = oracle.trace(oracle.default_config(128), bn, r, ne, te, nthreads=NCPU)
+    assert c.ray_steps == osteps
+    err = parity_err(e, oe)
+    print("128^3: %d ray-steps, parity err %.3e" % (osteps, err))
+    assert err < PARITY_TOL
+    assert np.array_equal(e == 0, oe == 0)
+    parts = tr.new_grid()
+    for s in range(8):
+        tr.launch(parts, shard_index=s, shard_count=8)
+    assert parity_err(parts.cpu().numpy(), oe) < PARITY_TOL
+    tr.close()
