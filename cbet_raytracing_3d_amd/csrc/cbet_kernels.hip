@@ -519,8 +519,9 @@ __device__ __forceinline__ double node_load(const double *base, unsigned idx)
 //   FLIP     : lane-dependent corner order (DEPOSIT 3; see the weights section)
 //   TWOBOX   : a second window adopts the lanes that leave the first (DEPOSIT 3, RL = 0, PRE = 0)
 //   IDX64    : node tables of >= 2^32 bytes (n > 812)
+//   ABSORB   : def.cuh:118 absorption == 1 (false: bookkeeping mode, launch_ray_XZ.cu:307-311)
 // ---------------------------------------------------------------------------------------------
-template <int DEPOSIT, int WL, int RL, int PRE, bool FLIP, bool TWOBOX, bool IDX64>
+template <int DEPOSIT, int WL, int RL, int PRE, bool FLIP, bool TWOBOX, bool IDX64, bool ABSORB>
 __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
 {
     constexpr int NSLOT = (DEPOSIT == 3) ? (TWOBOX ? 2 : 1) * MovingWindow<WL, RL>::NDOUBLES
@@ -622,6 +623,7 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
     if (alive) gather_stencil();
     double dv0 = 0.0, dv1 = 0.0, dv2 = 0.0;  // deferred slab sums (one per axis) and their nodes
     int dn0 = 0, dn1 = 0, dn2 = 0;
+    unsigned slabs_seen = 0;                 // wave-uniform: value of the slab counter when last drained
 
     for (int tt = 0; tt < a.nt; ++tt) {                        // :207
         const unsigned long long live_mask = __ballot(alive);
@@ -629,7 +631,7 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
         w_steps_miss += 1u << 16;
         unsigned slot[8], node[8];
         double wgt[8];
-        int hi = 0, hj = 0, hk = 0, sx = 1, sy = 1, sz = 1;
+        int hi = 0, hj = 0, hk = 0, ax = 0, ay = 0, az = 0;  // own node (haloed) and the lane's low corner
         int X0 = 0, X1 = 0, Y0 = 0, Y1 = 0, Z0 = 0, Z1 = 0;
         double fx = 0, fy = 0, fz = 0, kap = 0;
         if (alive) {
@@ -667,21 +669,24 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
             }
             cell = (unsigned)(__mul24(__mul24(s.ci, ny) + s.cj, nz) + s.ck);
             // :296-298 absorption coefficient at the new node, then the NEXT step's stencil
-            if (a.absorption == 1) kap = node_load<IDX64>(a.kap3d, cell);
+            if (ABSORB) kap = node_load<IDX64>(a.kap3d, cell);
             gather_stencil();
         }
-        if (DEPOSIT == 3) {
+        if (DEPOSIT == 3 && (w_slabs_wide >> 16) != slabs_seen) {  // scalar test: a slab was retired last step
             // last step's retired slabs go to HBM now, younger than this step's gathers
+            slabs_seen = w_slabs_wide >> 16;
 #ifndef CBET_EXPERIMENT_DROP_FLUSH_ATOMICS
             if (dv0 != 0.0) { global_add(&a.edep[dn0], dv0); dv0 = 0.0; }
             if (dv1 != 0.0) { global_add(&a.edep[dn1], dv1); dv1 = 0.0; }
             if (dv2 != 0.0) { global_add(&a.edep[dn2], dv2); dv2 = 0.0; }
+#else
+            dv0 = dv1 = dv2 = 0.0;
 #endif
         }
         if (alive) {
             // :299-311 absorbed energy
             double inc;
-            if (a.absorption == 1) {
+            if (ABSORB) {
                 inc = kap * s.uray;
                 s.uray -= inc;
             } else {
@@ -691,12 +696,15 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
             // node along that axis and F = d for the neighbour on the `sign` side (:329-336).
             const double ox = fx - s.ci - 0.5, oy = fy - s.cj - 0.5, oz = fz - s.ck - 0.5;
             const double dm = 1.0 - fabs(ox), dn = 1.0 - fabs(oy), dl = 1.0 - fabs(oz);
-            sx = (ox < 0) ? -1 : 1;
-            sy = (oy < 0) ? -1 : 1;
-            sz = (oz < 0) ? -1 : 1;
+            // :338-339 the neighbour lies on the side of the offset's sign, so a lane's two nodes per
+            // axis are {low, low + 1} with low = own - 1 when the offset is negative
+            const bool ngx = ox < 0, ngy = oy < 0, ngz = oz < 0;
             hi = s.ci + 1;
             hj = s.cj + 1;
             hk = s.ck + 1;
+            ax = hi - (ngx ? 1 : 0);
+            ay = hj - (ngy ? 1 : 0);
+            az = hk - (ngz ? 1 : 0);
             // Corner order.  The eight (node, weight) pairs are the same whatever order they are
             // enumerated in, and every product keeps the reference's operand order.  With FLIP, lane
             // bits 0/1/2 swap which of an axis's two nodes is visited first, so the 8 lanes of a
@@ -707,9 +715,11 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
             const double Fx0 = flx ? dm : ax_own, Fx1 = flx ? ax_own : dm;
             const double Fy0 = fly ? dn : ay_own, Fy1 = fly ? ay_own : dn;
             const double Fz0 = flz ? dl : az_own, Fz1 = flz ? az_own : dl;
-            X0 = flx ? hi + sx : hi; X1 = flx ? hi : hi + sx;
-            Y0 = fly ? hj + sy : hj; Y1 = fly ? hj : hj + sy;
-            Z0 = flz ? hk + sz : hk; Z1 = flz ? hk : hk + sz;
+            // first-visited node: the own node (high one iff the offset is negative) unless flipped
+            const bool hx = ngx != flx, hy = ngy != fly, hz = ngz != flz;
+            X0 = ax + (hx ? 1 : 0); X1 = ax + (hx ? 0 : 1);
+            Y0 = ay + (hy ? 1 : 0); Y1 = ay + (hy ? 0 : 1);
+            Z0 = az + (hz ? 1 : 0); Z1 = az + (hz ? 0 : 1);
             const double zy00 = Fz0 * Fy0, zy10 = Fz1 * Fy0, zy01 = Fz0 * Fy1, zy11 = Fz1 * Fy1;
             // order (x,y,z) = (0,0,0) (1,0,0) (0,0,1) (1,0,1) (0,1,0) (1,1,0) (0,1,1) (1,1,1) -- :341-348 without FLIP
             wgt[0] = zy00 * Fx0 * inc;
@@ -744,8 +754,7 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
         }
         if (DEPOSIT == 2) lds_deposit8<WL>(tagged, alive, slot, node, wgt, a.edep, n_evict);
         if (DEPOSIT == 3) {
-            // the lane's 8 targets span {h, h+s} per axis; its low corner is h + (s>>1)  (s>>1: -1 or 0)
-            const int ax = hi + (sx >> 1), ay = hj + (sy >> 1), az = hk + (sz >> 1);
+            // the lane's 8 targets span {low, low + 1} per axis; (ax, ay, az) is its low corner
             int wide = 0;
             using MW = MovingWindow<WL, RL>;
             bool inbox;            // the lane deposits into LDS this step
@@ -811,7 +820,7 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
             int key = inbox ? 0 : -2 - lane;
             if (PRE >= 1 && !FLIP) {
                 if (inbox)
-                    key = (int)(((__mul24(hi, sXh) + __mul24(hj, sYh) + hk) << 3) | ((sx & 2) << 1) | (sy & 2) | ((sz & 2) >> 1));
+                    key = (int)(((__mul24(hi, sXh) + __mul24(hj, sYh) + hk) << 3) | ((hi - ax) << 2) | ((hj - ay) << 1) | (hk - az));
                 merge_level<0xB1, 1>(lane, key, wgt);                 // quad_perm [1,0,3,2]: lane ^ 1
                 if (PRE >= 2) merge_level<0x4E, 2>(lane, key, wgt);   // quad_perm [2,3,0,1]: lane ^ 2
             }
@@ -900,43 +909,45 @@ hipError_t launch_tabulate(const TabulateArgs &a, hipStream_t stream)
     return hipGetLastError();
 }
 
-template <int RL, int PRE, bool FLIP, bool IDX64>
-static void launch_window8(const TraceArgs &a, dim3 grid, hipStream_t stream)
+template <int DEPOSIT, int WL, int RL, int PRE, bool FLIP, bool TWOBOX, bool IDX64>
+static void launch_k(const TraceArgs &a, dim3 grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL((k_trace<3, 3, RL, PRE, FLIP, false, IDX64>), grid, dim3(kWave), 0, stream, a);
+    if (a.absorption == 1)
+        hipLaunchKernelGGL((k_trace<DEPOSIT, WL, RL, PRE, FLIP, TWOBOX, IDX64, true>), grid, dim3(kWave), 0, stream, a);
+    else
+        hipLaunchKernelGGL((k_trace<DEPOSIT, WL, RL, PRE, FLIP, TWOBOX, IDX64, false>), grid, dim3(kWave), 0, stream, a);
 }
 
 template <bool IDX64>
 static void dispatch_trace(const TraceArgs &a, int variant, int wl, int rl, int pre, bool flip, bool twobox,
                            dim3 grid, hipStream_t stream)
 {
-    const dim3 block(kWave);
     if (variant == CBET_KERNEL_GLOBAL_ATOMICS) {
-        hipLaunchKernelGGL((k_trace<1, 1, 0, 0, false, false, IDX64>), grid, block, 0, stream, a);
+        launch_k<1, 1, 0, 0, false, false, IDX64>(a, grid, stream);
     } else if (variant == CBET_KERNEL_LDS_COMBINE) {
-        if (wl == 4) hipLaunchKernelGGL((k_trace<2, 4, 0, 0, false, false, IDX64>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((k_trace<2, 3, 0, 0, false, false, IDX64>), grid, block, 0, stream, a);
+        if (wl == 4) launch_k<2, 4, 0, 0, false, false, IDX64>(a, grid, stream);
+        else launch_k<2, 3, 0, 0, false, false, IDX64>(a, grid, stream);
     } else if (wl == 4) {
-        hipLaunchKernelGGL((k_trace<3, 4, 0, 0, false, false, IDX64>), grid, block, 0, stream, a);
+        launch_k<3, 4, 0, 0, false, false, IDX64>(a, grid, stream);
     } else if (twobox) {
-        hipLaunchKernelGGL((k_trace<3, 3, 0, 0, true, true, IDX64>), grid, block, 0, stream, a);
+        launch_k<3, 3, 0, 0, true, true, IDX64>(a, grid, stream);
     } else if (flip) {
         switch (rl) {
-        case 0: launch_window8<0, 0, true, IDX64>(a, grid, stream); break;
-        case 1: launch_window8<1, 0, true, IDX64>(a, grid, stream); break;
-        default: launch_window8<2, 0, true, IDX64>(a, grid, stream); break;
+        case 0: launch_k<3, 3, 0, 0, true, false, IDX64>(a, grid, stream); break;
+        case 1: launch_k<3, 3, 1, 0, true, false, IDX64>(a, grid, stream); break;
+        default: launch_k<3, 3, 2, 0, true, false, IDX64>(a, grid, stream); break;
         }
     } else {
         switch (rl * 3 + pre) {
-        case 0: launch_window8<0, 0, false, IDX64>(a, grid, stream); break;
-        case 1: launch_window8<0, 1, false, IDX64>(a, grid, stream); break;
-        case 2: launch_window8<0, 2, false, IDX64>(a, grid, stream); break;
-        case 3: launch_window8<1, 0, false, IDX64>(a, grid, stream); break;
-        case 4: launch_window8<1, 1, false, IDX64>(a, grid, stream); break;
-        case 5: launch_window8<1, 2, false, IDX64>(a, grid, stream); break;
-        case 6: launch_window8<2, 0, false, IDX64>(a, grid, stream); break;
-        case 7: launch_window8<2, 1, false, IDX64>(a, grid, stream); break;
-        default: launch_window8<2, 2, false, IDX64>(a, grid, stream); break;
+        case 0: launch_k<3, 3, 0, 0, false, false, IDX64>(a, grid, stream); break;
+        case 1: launch_k<3, 3, 0, 1, false, false, IDX64>(a, grid, stream); break;
+        case 2: launch_k<3, 3, 0, 2, false, false, IDX64>(a, grid, stream); break;
+        case 3: launch_k<3, 3, 1, 0, false, false, IDX64>(a, grid, stream); break;
+        case 4: launch_k<3, 3, 1, 1, false, false, IDX64>(a, grid, stream); break;
+        case 5: launch_k<3, 3, 1, 2, false, false, IDX64>(a, grid, stream); break;
+        case 6: launch_k<3, 3, 2, 0, false, false, IDX64>(a, grid, stream); break;
+        case 7: launch_k<3, 3, 2, 1, false, false, IDX64>(a, grid, stream); break;
+        default: launch_k<3, 3, 2, 2, false, false, IDX64>(a, grid, stream); break;
         }
     }
 }
