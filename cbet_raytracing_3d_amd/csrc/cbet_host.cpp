@@ -53,13 +53,25 @@ void note(DeviceJob &j, int rc)
 
 void release(DeviceJob &j)
 {
-    (void)hipSetDevice(j.gpu);
-    if (j.stream) (void)hipStreamDestroy(j.stream);
-    cbet_context_destroy(j.ctx);
-    for (double *p : {j.d_beam_norm, j.d_bbeam_norm, j.d_pow_r, j.d_phase_r, j.d_ne, j.d_te, j.d_r, j.d_edep})
-        if (p) (void)hipFree(p);
+    if (hipSetDevice(j.gpu) == hipSuccess) {
+        if (j.stream) (void)hipStreamDestroy(j.stream);
+        cbet_context_destroy(j.ctx);
+        for (double *p : {j.d_beam_norm, j.d_bbeam_norm, j.d_pow_r, j.d_phase_r, j.d_ne, j.d_te, j.d_r, j.d_edep})
+            if (p) (void)hipFree(p);
+    }
+    (void)hipGetLastError();  // a device that never existed must not leave a sticky error behind
 }
 
+}  // namespace
+
+namespace {
+// rayTracing() leaves the process on whatever device it touched last (and ends with
+// cudaDeviceReset, main.cu:217); here the caller's current device is restored instead.
+struct RestoreDevice {
+    int saved = -1;
+    RestoreDevice() { if (hipGetDevice(&saved) != hipSuccess) saved = -1; }
+    ~RestoreDevice() { if (saved >= 0) (void)hipSetDevice(saved); (void)hipGetLastError(); }
+};
 }  // namespace
 
 extern "C" int cbet_ray_tracing(const double *te_profile, const double *r_profile,
@@ -67,6 +79,7 @@ extern "C" int cbet_ray_tracing(const double *te_profile, const double *r_profil
                                 const double *beam_norm, const int *gpus, int ngpu, double *timers,
                                 cbet_counters *counters)
 {
+    RestoreDevice restore_device;
     if (!te_profile || !r_profile || !ne_profile || !edep || !p)
         return cbet::fail(CBET_EINVAL, "cbet_ray_tracing: NULL argument");
     if (ngpu < 1) return cbet::fail(CBET_EINVAL, "cbet_ray_tracing: ngpu < 1");
