@@ -427,7 +427,8 @@ struct MovingWindow {
                                                 int sXh, int sYh, int &n_at, int &n_wide, unsigned &n_slabs16,
                                                 double &dv, int &dn)
     {
-        // dead lanes get a neutral offset (mid-box), so no ballot needs the alive mask
+        // dead lanes get a neutral offset (mid-box), so no ballot needs the alive mask (masking the
+        // ballots on the scalar unit instead was measured slower: scalar-register pressure)
         const int rel = alive ? lo_corner - o : W / 2 - 1;
         // one ballot decides whether anything can happen: a lane on an edge cell or outside
         if (!any_lane((unsigned)(rel - 1) >= (unsigned)(S - 1))) return;
@@ -602,23 +603,29 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
         // wave-uniform branch.
         const bool on_face = (unsigned)(s.ci - 1) >= (unsigned)(nx - 2) || (unsigned)(s.cj - 1) >= (unsigned)(ny - 2) ||
                              (unsigned)(s.ck - 1) >= (unsigned)(nz - 2);
-        int oxm = -sX, oxp = sX, oym = -sY, oyp = sY, ozm = -1, ozp = 1;
         wave_on_face = __builtin_amdgcn_ballot_w64(on_face) != 0ull;
-        if (wave_on_face) {
-            oxm = (s.ci == 0) ? 0 : ((s.ci == nx - 1) ? -2 * sX : -sX);
-            oxp = (s.ci == 0) ? 2 * sX : ((s.ci == nx - 1) ? 0 : sX);
-            oym = (s.cj == 0) ? 0 : ((s.cj == ny - 1) ? -2 * sY : -sY);
-            oyp = (s.cj == 0) ? 2 * sY : ((s.cj == ny - 1) ? 0 : sY);
-            ozm = (s.ck == 0) ? 0 : ((s.ck == nz - 1) ? -2 : -1);
-            ozp = (s.ck == 0) ? 2 : ((s.ck == nz - 1) ? 0 : 1);
+        if (!wave_on_face) {
+            // :254-265 six gathers from the node table, scalar strides added straight into the address
+            st_xp = node_load<IDX64>(a.ne3d, cell + sX);
+            st_xm = node_load<IDX64>(a.ne3d, cell - sX);
+            st_yp = node_load<IDX64>(a.ne3d, cell + sY);
+            st_ym = node_load<IDX64>(a.ne3d, cell - sY);
+            st_zp = node_load<IDX64>(a.ne3d, cell + 1);
+            st_zm = node_load<IDX64>(a.ne3d, cell - 1);
+        } else {
+            const int oxm = (s.ci == 0) ? 0 : ((s.ci == nx - 1) ? -2 * sX : -sX);
+            const int oxp = (s.ci == 0) ? 2 * sX : ((s.ci == nx - 1) ? 0 : sX);
+            const int oym = (s.cj == 0) ? 0 : ((s.cj == ny - 1) ? -2 * sY : -sY);
+            const int oyp = (s.cj == 0) ? 2 * sY : ((s.cj == ny - 1) ? 0 : sY);
+            const int ozm = (s.ck == 0) ? 0 : ((s.ck == nz - 1) ? -2 : -1);
+            const int ozp = (s.ck == 0) ? 2 : ((s.ck == nz - 1) ? 0 : 1);
+            st_xp = node_load<IDX64>(a.ne3d, cell + oxp);
+            st_xm = node_load<IDX64>(a.ne3d, cell + oxm);
+            st_yp = node_load<IDX64>(a.ne3d, cell + oyp);
+            st_ym = node_load<IDX64>(a.ne3d, cell + oym);
+            st_zp = node_load<IDX64>(a.ne3d, cell + ozp);
+            st_zm = node_load<IDX64>(a.ne3d, cell + ozm);
         }
-        // :254-265 six gathers from the node table
-        st_xp = node_load<IDX64>(a.ne3d, cell + oxp);
-        st_xm = node_load<IDX64>(a.ne3d, cell + oxm);
-        st_yp = node_load<IDX64>(a.ne3d, cell + oyp);
-        st_ym = node_load<IDX64>(a.ne3d, cell + oym);
-        st_zp = node_load<IDX64>(a.ne3d, cell + ozp);
-        st_zm = node_load<IDX64>(a.ne3d, cell + ozm);
     };
     if (alive) gather_stencil();
     double dv0 = 0.0, dv1 = 0.0, dv2 = 0.0;  // deferred slab sums (one per axis) and their nodes
@@ -631,9 +638,11 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
         w_steps_miss += 1u << 16;
         unsigned slot[8], node[8];
         double wgt[8];
-        int hi = 0, hj = 0, hk = 0, ax = 0, ay = 0, az = 0;  // own node (haloed) and the lane's low corner
-        int X0 = 0, X1 = 0, Y0 = 0, Y1 = 0, Z0 = 0, Z1 = 0;
-        double fx = 0, fy = 0, fz = 0, kap = 0;
+        // Written and read by live lanes only (every later use is behind `alive`): deliberately left
+        // uninitialised so that no per-step moves are spent on values dead lanes never use.
+        int hi, hj, hk, ax, ay, az;  // own node (haloed) and the lane's low corner
+        int X0, X1, Y0, Y1, Z0, Z1;
+        double fx, fy, fz, kap;
         if (alive) {
             // :268-273 kick then drift (stencil values gathered during the previous step)
             s.vx -= a.xconst * (st_xp - st_xm);
