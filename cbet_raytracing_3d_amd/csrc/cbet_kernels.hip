@@ -693,13 +693,18 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
 #endif
         }
         if (alive) {
-            // :299-311 absorbed energy
-            double inc;
-            if (ABSORB) {
-                inc = kap * s.uray;
-                s.uray -= inc;
-            } else {
-                inc = s.uray;
+            // :299-311 absorbed energy.  For the windowed deposit the multiplication by `inc` is
+            // applied last (below, after the window logic): kappa was requested a few instructions
+            // ago and nothing from here to the deposit needs it, so a lone wave -- the tail of a
+            // short launch -- no longer stalls on that gather every step.
+            double inc = 0.0;
+            if (DEPOSIT != 3) {
+                if (ABSORB) {
+                    inc = kap * s.uray;
+                    s.uray -= inc;
+                } else {
+                    inc = s.uray;
+                }
             }
             // :319-339 weights.  Each weight is (Fz * Fy) * Fx * inc with F = (1-d) for the ray's own
             // node along that axis and F = d for the neighbour on the `sign` side (:329-336).
@@ -731,14 +736,18 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
             Z0 = az + (hz ? 1 : 0); Z1 = az + (hz ? 0 : 1);
             const double zy00 = Fz0 * Fy0, zy10 = Fz1 * Fy0, zy01 = Fz0 * Fy1, zy11 = Fz1 * Fy1;
             // order (x,y,z) = (0,0,0) (1,0,0) (0,0,1) (1,0,1) (0,1,0) (1,1,0) (0,1,1) (1,1,1) -- :341-348 without FLIP
-            wgt[0] = zy00 * Fx0 * inc;
-            wgt[1] = zy00 * Fx1 * inc;
-            wgt[2] = zy10 * Fx0 * inc;
-            wgt[3] = zy10 * Fx1 * inc;
-            wgt[4] = zy01 * Fx0 * inc;
-            wgt[5] = zy01 * Fx1 * inc;
-            wgt[6] = zy11 * Fx0 * inc;
-            wgt[7] = zy11 * Fx1 * inc;
+            wgt[0] = zy00 * Fx0;
+            wgt[1] = zy00 * Fx1;
+            wgt[2] = zy10 * Fx0;
+            wgt[3] = zy10 * Fx1;
+            wgt[4] = zy01 * Fx0;
+            wgt[5] = zy01 * Fx1;
+            wgt[6] = zy11 * Fx0;
+            wgt[7] = zy11 * Fx1;
+            if (DEPOSIT != 3) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) wgt[c] = wgt[c] * inc;   // a_c * increment, :341-348
+            }
             if (DEPOSIT != 3) {
                 const int nX0 = __mul24(X0, sXh), nX1 = __mul24(X1, sXh), nY0 = __mul24(Y0, sYh), nY1 = __mul24(Y1, sYh);
                 node[0] = nX0 + nY0 + Z0; node[1] = nX1 + nY0 + Z0; node[2] = nX0 + nY0 + Z1; node[3] = nX1 + nY0 + Z1;
@@ -823,6 +832,17 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
             if (__builtin_amdgcn_ballot_w64(alive && !inbox) != 0ull) {
                 w_steps_miss += 1u;
                 if (!TWOBOX && wide) w_slabs_wide += 1u;
+            }
+            if (alive) {  // :305-311, then a_c * increment (:341-348)
+                double inc;
+                if (ABSORB) {
+                    inc = kap * s.uray;
+                    s.uray -= inc;
+                } else {
+                    inc = s.uray;
+                }
+#pragma unroll
+                for (int c = 0; c < 8; ++c) wgt[c] = wgt[c] * inc;
             }
             // key: identifies the ordered set of 8 target nodes (own node + the three signs); lanes may
             // only be merged when they enumerate the corners in the same order, i.e. without FLIP
