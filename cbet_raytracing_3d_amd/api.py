@@ -47,7 +47,7 @@ class Params(C.Structure):
         ("kernel_variant", C.c_int), ("lds_window_log2", C.c_int), ("lds_copies_log2", C.c_int),
         ("lds_prereduce", C.c_int), ("lds_corner_flip", C.c_int),
         ("lds_two_boxes", C.c_int), ("force_wide_index", C.c_int), ("xcd_order", C.c_int),
-        ("patch_order", C.c_int),
+        ("per_beam_grids", C.c_int), ("patch_order", C.c_int),
     ]
 
     def copy(self, **overrides):

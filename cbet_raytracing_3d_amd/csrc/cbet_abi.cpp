@@ -564,6 +564,7 @@ int cbet_trace_nodes(int b, unsigned nindices, const double *ne3d, const double 
     a.kap3d = kappa3d ? kappa3d : ctx->kap3d;
     a.beam_norm = beam_norm; a.bbeam_norm = bbeam_norm; a.pow_r = pow_r; a.phase_r = phase_r;
     a.edep = edep;
+    a.grid_stride = p->per_beam_grids ? d.edep_size : 0;
     a.counters = ctx->counters;
 
     DeviceGuard guard;

@@ -66,6 +66,7 @@ struct TraceArgs {
     const double *ne3d, *kap3d;
     const double *beam_norm, *bbeam_norm, *pow_r, *phase_r;
     double *edep;
+    long grid_stride;                       // 0: one grid for all beams; else doubles between per-beam grids
     unsigned long long *counters;
 };
 

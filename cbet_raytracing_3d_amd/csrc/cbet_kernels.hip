@@ -549,6 +549,9 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
     const long g = a.shard_index + (long)a.shard_count * w;
     if (g >= a.total_bundles) return;  // wave-uniform
     const int beam = a.beam_lo + (int)(g / a.bundles_per_beam);
+    // beam-resolved deposition (cbet_params.per_beam_grids): beam b accumulates into its own grid,
+    // edep[b * grid_stride ...]; otherwise every beam adds into the one grid (grid_stride = 0)
+    double *const edep = a.edep + (long)beam * a.grid_stride;
     const int li = (int)(g % a.bundles_per_beam) * kWave + lane;
 
     Ray s;
@@ -685,9 +688,9 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
             // last step's retired slabs go to HBM now, younger than this step's gathers
             slabs_seen = w_slabs_wide >> 16;
 #ifndef CBET_EXPERIMENT_DROP_FLUSH_ATOMICS
-            if (dv0 != 0.0) { global_add(&a.edep[dn0], dv0); dv0 = 0.0; }
-            if (dv1 != 0.0) { global_add(&a.edep[dn1], dv1); dv1 = 0.0; }
-            if (dv2 != 0.0) { global_add(&a.edep[dn2], dv2); dv2 = 0.0; }
+            if (dv0 != 0.0) { global_add(&edep[dn0], dv0); dv0 = 0.0; }
+            if (dv1 != 0.0) { global_add(&edep[dn1], dv1); dv1 = 0.0; }
+            if (dv2 != 0.0) { global_add(&edep[dn2], dv2); dv2 = 0.0; }
 #else
             dv0 = dv1 = dv2 = 0.0;
 #endif
@@ -755,7 +758,7 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
             }
             if (DEPOSIT == 1) {
 #pragma unroll
-                for (int c = 0; c < 8; ++c) global_add(&a.edep[node[c]], wgt[c]);
+                for (int c = 0; c < 8; ++c) global_add(&edep[node[c]], wgt[c]);
                 n_atomics += 8;
             }
             if (DEPOSIT == 2) {
@@ -770,7 +773,7 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
             }
             ++nsteps;
         }
-        if (DEPOSIT == 2) lds_deposit8<WL>(tagged, alive, slot, node, wgt, a.edep, n_evict);
+        if (DEPOSIT == 2) lds_deposit8<WL>(tagged, alive, slot, node, wgt, edep, n_evict);
         if (DEPOSIT == 3) {
             // the lane's 8 targets span {low, low + 1} per axis; (ax, ay, az) is its low corner
             int wide = 0;
@@ -778,17 +781,17 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
             bool inbox;            // the lane deposits into LDS this step
             int tile = 0;          // ... into this tile (offset in doubles)
             if (!TWOBOX) {
-                win.template follow_axis<0, true>(win.ox, alive, ax, lane, a.edep, sXh, sYh, n_atomics, wide, w_slabs_wide, dv0, dn0);
-                win.template follow_axis<1, true>(win.oy, alive, ay, lane, a.edep, sXh, sYh, n_atomics, wide, w_slabs_wide, dv1, dn1);
-                win.template follow_axis<2, true>(win.oz, alive, az, lane, a.edep, sXh, sYh, n_atomics, wide, w_slabs_wide, dv2, dn2);
+                win.template follow_axis<0, true>(win.ox, alive, ax, lane, edep, sXh, sYh, n_atomics, wide, w_slabs_wide, dv0, dn0);
+                win.template follow_axis<1, true>(win.oy, alive, ay, lane, edep, sXh, sYh, n_atomics, wide, w_slabs_wide, dv1, dn1);
+                win.template follow_axis<2, true>(win.oz, alive, az, lane, edep, sXh, sYh, n_atomics, wide, w_slabs_wide, dv2, dn2);
                 __builtin_amdgcn_wave_barrier();
                 inbox = alive && win.holds(ax, ay, az);
             } else {
                 // box A follows the lanes whose home it is
                 const bool memA = alive && !homeB;
-                win.template follow_axis<0, true>(win.ox, memA, ax, lane, a.edep, sXh, sYh, n_atomics, wide, w_slabs_wide, dv0, dn0);
-                win.template follow_axis<1, true>(win.oy, memA, ay, lane, a.edep, sXh, sYh, n_atomics, wide, w_slabs_wide, dv1, dn1);
-                win.template follow_axis<2, true>(win.oz, memA, az, lane, a.edep, sXh, sYh, n_atomics, wide, w_slabs_wide, dv2, dn2);
+                win.template follow_axis<0, true>(win.ox, memA, ax, lane, edep, sXh, sYh, n_atomics, wide, w_slabs_wide, dv0, dn0);
+                win.template follow_axis<1, true>(win.oy, memA, ay, lane, edep, sXh, sYh, n_atomics, wide, w_slabs_wide, dv1, dn1);
+                win.template follow_axis<2, true>(win.oz, memA, az, lane, edep, sXh, sYh, n_atomics, wide, w_slabs_wide, dv2, dn2);
                 const bool inA = alive && win.holds(ax, ay, az);
                 bool inB = false;
                 if (b_active) {  // scalar branch
@@ -796,9 +799,9 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
                     const bool memB = alive && homeB;
                     double tv = 0.0;
                     int tn = 0, tw = 0;
-                    winB.template follow_axis<0, false>(winB.ox, memB, ax, lane, a.edep, sXh, sYh, n_atomics, tw, w_slabs_wide, tv, tn);
-                    winB.template follow_axis<1, false>(winB.oy, memB, ay, lane, a.edep, sXh, sYh, n_atomics, tw, w_slabs_wide, tv, tn);
-                    winB.template follow_axis<2, false>(winB.oz, memB, az, lane, a.edep, sXh, sYh, n_atomics, tw, w_slabs_wide, tv, tn);
+                    winB.template follow_axis<0, false>(winB.ox, memB, ax, lane, edep, sXh, sYh, n_atomics, tw, w_slabs_wide, tv, tn);
+                    winB.template follow_axis<1, false>(winB.oy, memB, ay, lane, edep, sXh, sYh, n_atomics, tw, w_slabs_wide, tv, tn);
+                    winB.template follow_axis<2, false>(winB.oz, memB, az, lane, edep, sXh, sYh, n_atomics, tw, w_slabs_wide, tv, tn);
                     inB = alive && winB.holds(ax, ay, az);
                 }
                 // lanes that fell out of A look for a home in B; an idle B is re-created around the first of them
@@ -820,7 +823,7 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
                     if (alive && homeB && !inB && inA) homeB = false;
                     if (__builtin_amdgcn_ballot_w64(alive && homeB) == 0ull) {
                         __builtin_amdgcn_wave_barrier();
-                        winB.flush_all(lane, a.edep, sXh, sYh, n_atomics);
+                        winB.flush_all(lane, edep, sXh, sYh, n_atomics);
                         b_active = false;
                     }
                 }
@@ -869,14 +872,14 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
             } else if (alive && !inbox) {
 #ifndef CBET_EXPERIMENT_DROP_MISS_ATOMICS  // timing-only experiment builds; never shipped
                 const int nX0 = __mul24(X0, sXh), nX1 = __mul24(X1, sXh), nY0 = __mul24(Y0, sYh), nY1 = __mul24(Y1, sYh);
-                global_add(&a.edep[nX0 + nY0 + Z0], wgt[0]);
-                global_add(&a.edep[nX1 + nY0 + Z0], wgt[1]);
-                global_add(&a.edep[nX0 + nY0 + Z1], wgt[2]);
-                global_add(&a.edep[nX1 + nY0 + Z1], wgt[3]);
-                global_add(&a.edep[nX0 + nY1 + Z0], wgt[4]);
-                global_add(&a.edep[nX1 + nY1 + Z0], wgt[5]);
-                global_add(&a.edep[nX0 + nY1 + Z1], wgt[6]);
-                global_add(&a.edep[nX1 + nY1 + Z1], wgt[7]);
+                global_add(&edep[nX0 + nY0 + Z0], wgt[0]);
+                global_add(&edep[nX1 + nY0 + Z0], wgt[1]);
+                global_add(&edep[nX0 + nY0 + Z1], wgt[2]);
+                global_add(&edep[nX1 + nY0 + Z1], wgt[3]);
+                global_add(&edep[nX0 + nY1 + Z0], wgt[4]);
+                global_add(&edep[nX1 + nY1 + Z0], wgt[5]);
+                global_add(&edep[nX0 + nY1 + Z1], wgt[6]);
+                global_add(&edep[nX1 + nY1 + Z1], wgt[7]);
 #endif
                 n_atomics += 8;
                 ++n_evict;  // counted as "ray-steps that missed the window"
@@ -899,15 +902,15 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
 
     if (DEPOSIT == 2) {
         __syncthreads();
-        n_atomics += tagged.flush(lane, a.edep) + n_evict;
+        n_atomics += tagged.flush(lane, edep) + n_evict;
     }
     if (DEPOSIT == 3) {
-        if (dv0 != 0.0) global_add(&a.edep[dn0], dv0);
-        if (dv1 != 0.0) global_add(&a.edep[dn1], dv1);
-        if (dv2 != 0.0) global_add(&a.edep[dn2], dv2);
+        if (dv0 != 0.0) global_add(&edep[dn0], dv0);
+        if (dv1 != 0.0) global_add(&edep[dn1], dv1);
+        if (dv2 != 0.0) global_add(&edep[dn2], dv2);
         __syncthreads();
-        win.flush_all(lane, a.edep, sXh, sYh, n_atomics);
-        if (TWOBOX && b_active) winB.flush_all(lane, a.edep, sXh, sYh, n_atomics);
+        win.flush_all(lane, edep, sXh, sYh, n_atomics);
+        if (TWOBOX && b_active) winB.flush_all(lane, edep, sXh, sYh, n_atomics);
     }
     // counters: one atomic per wave and counter
     const int tot_steps = wave_sum(nsteps), tot_rays = wave_sum(launched), tot_at = wave_sum(n_atomics),
@@ -1005,7 +1008,8 @@ hipError_t launch_trace(const TraceArgs &a, int variant, int window_log2, int co
     if (waves <= 0) return hipSuccess;
 #ifdef CBET_DEBUG_BOUNDS
     {
-        const double *lo = a.edep, *hi = a.edep + (long)(a.nx + 2) * (a.ny + 2) * (a.nz + 2);
+        const long cells = (long)(a.nx + 2) * (a.ny + 2) * (a.nz + 2);
+        const double *lo = a.edep, *hi = a.edep + (a.grid_stride ? a.grid_stride * (long)(a.beam_lo + a.nbeams_local) : cells);
         const unsigned long long nodes = (unsigned long long)a.nx * a.ny * a.nz;
         (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_audit_edep_lo), &lo, sizeof lo, 0, hipMemcpyHostToDevice, stream);
         (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_audit_edep_hi), &hi, sizeof hi, 0, hipMemcpyHostToDevice, stream);

@@ -49,17 +49,21 @@ class RayTracer:
         self.ctx = api.Context(self.params, self.gpu)
         self.grid_shape = (self.params.nx + 2, self.params.ny + 2, self.params.nz + 2)
 
-    def new_grid(self):
-        return torch.zeros(self.grid_shape, dtype=torch.float64, device=self.device)
+    def new_grid(self, per_beam=False):
+        """A zeroed deposition grid; per_beam=True: one grid per beam (cbet_params.per_beam_grids)."""
+        shape = ((self.params.nbeams,) + self.grid_shape) if per_beam else self.grid_shape
+        return torch.zeros(shape, dtype=torch.float64, device=self.device)
 
     def launch(self, edep, shard_index=0, shard_count=1, beam_lo=0, beam_hi=None,
                kernel_variant=None, lds_window_log2=None, lds_copies_log2=None, lds_prereduce=None,
                lds_corner_flip=None, lds_two_boxes=None, force_wide_index=None, xcd_order=None,
                use_host_trig=True):
         """Enqueue one launch_ray_XYZ on torch's current stream, accumulating into `edep`."""
-        if edep.dtype != torch.float64 or not edep.is_contiguous() or tuple(edep.shape) != self.grid_shape:
-            raise ValueError("edep must be a contiguous float64 tensor of shape %s" % (self.grid_shape,))
-        p = self.params.copy(beam_lo=beam_lo,
+        per_beam = edep.dim() == 4
+        want = ((self.params.nbeams,) + self.grid_shape) if per_beam else self.grid_shape
+        if edep.dtype != torch.float64 or not edep.is_contiguous() or tuple(edep.shape) != want:
+            raise ValueError("edep must be a contiguous float64 tensor of shape %s (or nbeams x that)" % (self.grid_shape,))
+        p = self.params.copy(per_beam_grids=1 if per_beam else 0, beam_lo=beam_lo,
                              beam_hi=self.params.nbeams if beam_hi is None else beam_hi,
                              shard_index=shard_index, shard_count=shard_count)
         if kernel_variant is not None:

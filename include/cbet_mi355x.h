@@ -73,6 +73,9 @@ typedef struct cbet_params {
                                  /* with 8*nx*ny*nz >= 2^32 bytes (n > 812) need, at any size      */
     int xcd_order;               /* workgroup order: 1 = consecutive bundles on one XCD, 0 = plain, */
                                  /* -1 = auto                                                       */
+    int per_beam_grids;          /* 1: beam-resolved deposition -- edep is nbeams grids of            */
+                                 /* (nx+2)(ny+2)(nz+2) doubles and beam b adds into grid b (what a    */
+                                 /* cross-beam stage needs: every beam's own field); 0: one grid      */
     int patch_order;             /* launch-list order of the 8x8-ray patches of a beam: 1 = longest  */
                                  /* rays (largest launch radius) first, 0 = Morton curve.  Part of   */
                                  /* the geometry a context is created for.                           */
@@ -183,7 +186,8 @@ int cbet_debug_bounds_violations(unsigned long long *out, int reset, void *strea
  *   nindices   strided passes per thread (def.cuh:129) -- enters the traced-id rule only
  *   te_data_g, r_data_g, ne_data_g   device, nprofile doubles each (main.cu:149-151)
  *   edep       device, (nx+2)(ny+2)(nz+2) doubles, x-major/z-fastest with a one-cell halo
- *              (launch_ray_XZ.cu:5-7); ACCUMULATED into, never cleared (caller zeroes it)
+ *              (launch_ray_XZ.cu:5-7); ACCUMULATED into, never cleared (caller zeroes it).
+ *              With params->per_beam_grids: nbeams such grids, beam b's at offset b * grid size.
  *   bbeam_norm device, 4*nbeams doubles from cbet_host_beam_trig; the reference uploads but
  *              ignores it (main.cu:146) -- here it supplies the rotation cos/sin so that launch
  *              points equal the host libm's to the last bit.  NULL: trig evaluated on the device.

@@ -486,3 +486,31 @@ def test_full_grid_parity_128(api, oracle, inputs, torch_cuda):
         tr.launch(parts, shard_index=s, shard_count=8)
     assert parity_err(parts.cpu().numpy(), oe) < PARITY_TOL
     tr.close()
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_beam_resolved_deposition(api, oracle, inputs, torch_cuda, variant):
+    """per_beam_grids: every beam accumulates into its own grid (what a cross-beam stage consumes).
+    Beams are independent in the reference physics, so grid b must equal the oracle's trace of beam b
+    alone, and the grids must add up to the ordinary single-grid result."""
+    bn, r, ne, te = inputs
+    beams = [4, 17, 30, 43, 56]
+    tr = make_tracer(api, inputs, 48, beams=beams)
+    one, c1 = run(tr, torch_cuda, kernel_variant=variant)
+    per = tr.new_grid(per_beam=True)
+    tr.counters(reset=True)
+    tr.launch(per, kernel_variant=variant)
+    c = tr.counters(reset=True)
+    per = per.cpu().numpy()
+    assert per.shape == (5, 50, 50, 50) and c.ray_steps == c1.ray_steps
+    assert parity_err(per.sum(0), one) < 1e-11
+    cfg = oracle.default_config(48, nbeams=5)
+    for b in range(5):
+        oe, _ = oracle.trace(cfg, bn[beams].copy(), r, ne, te, beam_lo=b, beam_hi=b + 1, nthreads=NCPU)
+        assert parity_err(per[b], oe) < PARITY_TOL, b
+    # sharded + beam range: only the requested beams' grids are touched
+    part = tr.new_grid(per_beam=True)
+    tr.launch(part, kernel_variant=variant, beam_lo=1, beam_hi=3, shard_index=1, shard_count=2)
+    part = part.cpu().numpy()
+    assert float(np.abs(part[[0, 3, 4]]).sum()) == 0.0 and part[1].sum() > 0 and part[2].sum() > 0
+    tr.close()
