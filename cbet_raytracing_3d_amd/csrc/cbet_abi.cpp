@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -234,6 +235,7 @@ int cbet_params_default(cbet_params *p, int n)
     p->lds_two_boxes = -1;
     p->xcd_order = -1;
     p->patch_order = 1;
+    p->order_phases = -1;
     return CBET_OK;
 }
 
@@ -559,6 +561,14 @@ int cbet_trace_nodes(int b, unsigned nindices, const double *ne3d, const double 
     a.total_bundles = (long)a.nbeams_local * a.bundles_per_beam;
     a.shard_index = p->shard_count > 1 ? p->shard_index : 0;
     a.shard_count = p->shard_count > 1 ? p->shard_count : 1;
+    // work-item order (cbet_params.order_phases; auto: 1 = plain beam-major, the fastest measured)
+    {
+        int phases = p->patch_order != 0 ? (p->order_phases < 1 ? 1 : p->order_phases) : 1;
+        if (phases > a.bundles_per_beam) phases = a.bundles_per_beam;
+        a.phase_len = (a.bundles_per_beam + phases - 1) / phases;
+        while (phases > 1 && (phases - 1) * a.phase_len >= a.bundles_per_beam) --phases;  // last phase non-empty
+        a.phases = phases;
+    }
     a.xcd_chunk = p->xcd_order > 0 ? 1 : 0;  // launch_trace turns the flag into the chunk length
     a.ne3d = ne3d ? ne3d : ctx->ne3d;
     a.kap3d = kappa3d ? kappa3d : ctx->kap3d;
@@ -566,6 +576,13 @@ int cbet_trace_nodes(int b, unsigned nindices, const double *ne3d, const double 
     a.edep = edep;
     a.grid_stride = p->per_beam_grids ? d.edep_size : 0;
     a.counters = ctx->counters;
+    a.timeline = nullptr;
+#ifdef CBET_EXPERIMENT_TIMELINE
+    {   // diagnostic builds: the caller passes a device buffer of 3 x workgroups u64 through the environment
+        const char *env = std::getenv("CBET_TIMELINE_PTR");
+        if (env) a.timeline = (unsigned long long *)std::strtoull(env, nullptr, 0);
+    }
+#endif
 
     DeviceGuard guard;
     CBET_HIP(hipSetDevice(ctx->gpu));

@@ -61,6 +61,7 @@ struct TraceArgs {
     int beam_lo, nbeams_local, bundles_per_beam;
     long total_bundles;
     int shard_index, shard_count;
+    int phases, phase_len;                  // work-item order: see k_trace (phases >= 1, phase_len = patches per phase)
     int xcd_chunk;                          // > 0: XCD-aware workgroup -> work-item map (see k_trace)
     // tables
     const double *ne3d, *kap3d;
@@ -68,6 +69,7 @@ struct TraceArgs {
     double *edep;
     long grid_stride;                       // 0: one grid for all beams; else doubles between per-beam grids
     unsigned long long *counters;
+    unsigned long long *timeline;           // diagnostic builds only: 3 words per workgroup, else NULL
 };
 
 hipError_t launch_tabulate(const TabulateArgs &a, hipStream_t stream);

@@ -537,6 +537,9 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
     if (a.nt < 0) s_pad[lane] = 1.0;  // keep the allocation alive
 #endif
 
+#ifdef CBET_EXPERIMENT_TIMELINE  // diagnostic builds only (scripts/experiment_timeline.sh): wave start/end stamps
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+#endif
     // which bundle: interleaved sharding over (beam, bundle) pairs.  Workgroups are dealt round-robin
     // over the 8 XCDs (b and b+8 share an L2); with xcd_chunk > 0 workgroup b takes work item
     // (b % 8) * xcd_chunk + b / 8, so that consecutive bundles -- neighbouring patches of one beam,
@@ -548,11 +551,26 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
     }
     const long g = a.shard_index + (long)a.shard_count * w;
     if (g >= a.total_bundles) return;  // wave-uniform
-    const int beam = a.beam_lo + (int)(g / a.bundles_per_beam);
+    // (beam, patch) of work item g.  Default (phases = 1): beam-major -- consecutive waves are
+    // neighbouring patches of one beam and share node-table lines in L2/MALL.  With phases > 1,
+    // phase p covers patches [p * phase_len, (p+1) * phase_len) of EVERY beam, beam by beam: a
+    // globally longest-first order that ends the launch on short bundles (the drain of a short launch
+    // is ~1.2 ms of waiting for the last beam's long bundles, scripts/experiment_timeline.py) -- but it
+    // was measured slower overall (cbet_params.order_phases), as was pure patch-major order (-17 %).
+    int beam_local, patch;
+    {
+        const long phase_items = (long)a.nbeams_local * a.phase_len;   // items in every phase but the last
+        const int ph = (int)min((long)(a.phases - 1), g / phase_items);
+        const long rem = g - ph * phase_items;
+        const int len = (ph < a.phases - 1) ? a.phase_len : a.bundles_per_beam - (a.phases - 1) * a.phase_len;
+        beam_local = (int)(rem / len);
+        patch = ph * a.phase_len + (int)(rem % len);
+    }
+    const int beam = a.beam_lo + beam_local;
     // beam-resolved deposition (cbet_params.per_beam_grids): beam b accumulates into its own grid,
     // edep[b * grid_stride ...]; otherwise every beam adds into the one grid (grid_stride = 0)
     double *const edep = a.edep + (long)beam * a.grid_stride;
-    const int li = (int)(g % a.bundles_per_beam) * kWave + lane;
+    const int li = patch * kWave + lane;
 
     Ray s;
     const int pre_raynum = li < a.nlive ? a.live[li] : -1;  // -1: hole in the 8x8 patch
@@ -912,6 +930,13 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
         win.flush_all(lane, edep, sXh, sYh, n_atomics);
         if (TWOBOX && b_active) winB.flush_all(lane, edep, sXh, sYh, n_atomics);
     }
+#ifdef CBET_EXPERIMENT_TIMELINE
+    if (lane == 0 && a.timeline) {
+        a.timeline[3 * (long)blockIdx.x + 0] = t_start;
+        a.timeline[3 * (long)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        a.timeline[3 * (long)blockIdx.x + 2] = (unsigned long long)(w_steps_miss >> 16);
+    }
+#endif
     // counters: one atomic per wave and counter
     const int tot_steps = wave_sum(nsteps), tot_rays = wave_sum(launched), tot_at = wave_sum(n_atomics),
               tot_ev = wave_sum(n_evict);

@@ -76,9 +76,15 @@ typedef struct cbet_params {
     int per_beam_grids;          /* 1: beam-resolved deposition -- edep is nbeams grids of            */
                                  /* (nx+2)(ny+2)(nz+2) doubles and beam b adds into grid b (what a    */
                                  /* cross-beam stage needs: every beam's own field); 0: one grid      */
-    int patch_order;             /* launch-list order of the 8x8-ray patches of a beam: 1 = longest  */
-                                 /* rays (largest launch radius) first, 0 = Morton curve.  Part of   */
-                                 /* the geometry a context is created for.                           */
+    int patch_order;             /* 1 = longest first: a beam's patches are listed by descending      */
+                                 /* launch radius (outer rays take ~3x the steps of central ones);     */
+                                 /* 0 = Morton curve.  Part of the geometry a context is created for.  */
+    int order_phases;            /* work-item order.  1 (and -1 = auto): beam-major -- beam by beam,   */
+                                 /* each beam's patches longest first.  P > 1: the launch runs in P    */
+                                 /* phases, phase p tracing the p-th slice of every beam's patch list  */
+                                 /* (a globally longest-first order that shortens a launch's tail);    */
+                                 /* measured slower (P = 2: -9 %): it bunches every beam's central     */
+                                 /* bundles, whose deposits hit the same cells, into the last phase.   */
 } cbet_params;
 
 /* Quantities the reference derives in def.cuh / main.cu:156-161, evaluated in the same order. */
@@ -127,8 +133,10 @@ int cbet_derive(const cbet_params *p, cbet_derived *d);
  * section is cut into 8x8-ray patches (Morton order); 64 consecutive entries = one patch = one ray
  * bundle = one wavefront.  An entry is the thread-ray id (launch_ray_XZ.cu:125,156) of that ray,
  * or -1 for a hole: a ray the reference launch shape never visits or one that fails init()'s
- * beam-radius test (:94,114).  Bundle g = beam_local * (n/64) + entry/64 is traced by shard
- * g % shard_count.  Writes min(n, cap) entries to out (may be NULL) and n to *count.
+ * beam-radius test (:94,114).  Work items g are (beam, patch) pairs ordered in phases
+ * (cbet_params.order_phases: phase by phase, beam by beam, patch by patch); item g is traced by shard
+ * g % shard_count.
+ * Writes min(n, cap) entries to out (may be NULL) and n to *count.
  */
 int cbet_live_ray_list(const cbet_params *p, int *out, long cap, long *count);
 
