@@ -20,7 +20,7 @@ HEADERS = [os.path.join(CSRC, "cbet_device.h"), os.path.join(CSRC, "cbet_relocat
 # -ffp-contract=off: a ray's fp64 arithmetic must be the reference's operation sequence (no fused
 # multiply-add), see cbet_kernels.hip.  No -ffast-math: fp64 div/sqrt stay correctly rounded.
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared",
-         "-Wall", "-Wno-unused-result"]
+         "-Wall", "-Wextra", "-Wno-unused-result"]
 
 
 def hipcc():

@@ -547,7 +547,7 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
     long w = blockIdx.x;
     if (a.xcd_chunk > 0) {
         w = (long)(blockIdx.x & 7) * a.xcd_chunk + (blockIdx.x >> 3);
-        if ((blockIdx.x >> 3) >= a.xcd_chunk) return;
+        if ((int)(blockIdx.x >> 3) >= a.xcd_chunk) return;
     }
     const long g = a.shard_index + (long)a.shard_count * w;
     if (g >= a.total_bundles) return;  // wave-uniform
@@ -659,11 +659,19 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
         w_steps_miss += 1u << 16;
         unsigned slot[8], node[8];
         double wgt[8];
-        // Written and read by live lanes only (every later use is behind `alive`): deliberately left
-        // uninitialised so that no per-step moves are spent on values dead lanes never use.
+        // Written and read by live lanes only (every later use is behind `alive`).  Dead lanes get "any
+        // value" (a frozen unspecified value: well defined, and no per-step moves are spent on it).
         int hi, hj, hk, ax, ay, az;  // own node (haloed) and the lane's low corner
         int X0, X1, Y0, Y1, Z0, Z1;
         double fx, fy, fz, kap;
+        hi = __builtin_nondeterministic_value(hi); hj = __builtin_nondeterministic_value(hj);
+        hk = __builtin_nondeterministic_value(hk); ax = __builtin_nondeterministic_value(ax);
+        ay = __builtin_nondeterministic_value(ay); az = __builtin_nondeterministic_value(az);
+        X0 = __builtin_nondeterministic_value(X0); X1 = __builtin_nondeterministic_value(X1);
+        Y0 = __builtin_nondeterministic_value(Y0); Y1 = __builtin_nondeterministic_value(Y1);
+        Z0 = __builtin_nondeterministic_value(Z0); Z1 = __builtin_nondeterministic_value(Z1);
+        fx = __builtin_nondeterministic_value(fx); fy = __builtin_nondeterministic_value(fy);
+        fz = __builtin_nondeterministic_value(fz); kap = __builtin_nondeterministic_value(kap);
         if (alive) {
             // :268-273 kick then drift (stencil values gathered during the previous step)
             s.vx -= a.xconst * (st_xp - st_xm);
