@@ -230,6 +230,7 @@ typedef struct ray_ctx {
     const cbet_oracle_config *cfg;
     cbet_oracle_derived d;
     const double *beam_norm, *r, *ne, *te, *pow_r, *phase_r;
+    const double *ne3d, *kap3d; /* optional node tables (3-D plasma): replace the radial lookups */
     double *edep;
     int atomic;
     double *path; /* optional KAT recording, 8 doubles per step */
@@ -277,7 +278,11 @@ static int trace_one(const ray_ctx *c, int beam, int pre_raynum)
 
     /* :186-204 |k| from the dispersion relation at the launch node, direction = -beam normal */
     double rad = sqrt(sq(ci * dx + xmin) + sq(cj * dy + ymin) + sq(ck * dz + zmin));
-    double ne0 = cbet_oracle_interp(c->ne, c->r, rad, nr);
+    /* node value: from the caller's node table when one is given (the 3-D plasma entry of the
+     * product), otherwise interpolated at the node's radius as the reference does */
+#define NODE_NE(i_, j_, k_, radius_) \
+    (c->ne3d ? c->ne3d[((long)(i_) * ny + (j_)) * nz + (k_)] : cbet_oracle_interp(c->ne, c->r, (radius_), nr))
+    double ne0 = NODE_NE(ci, cj, ck, rad);
     double w = sqrt((sq(d->omega) - ne0 * 1e6 * sq(K_EC) / ((double)K_ME * K_E0)) / sq(K_C));
     double vx = -1 * c->beam_norm[beam * 3 + 0];
     double vy = -1 * c->beam_norm[beam * 3 + 1];
@@ -301,12 +306,12 @@ static int trace_one(const ray_ctx *c, int beam, int pre_raynum)
         double zp_ = kp * dz + zmin, zm_ = km * dz + zmin, zc_ = ck * dz + zmin;
 
         /* :254-265 density at the six face neighbours of the node the ray sits at before moving */
-        double ne_xp = cbet_oracle_interp(c->ne, c->r, sqrt(xp_ * xp_ + yc_ * yc_ + zc_ * zc_), nr);
-        double ne_xm = cbet_oracle_interp(c->ne, c->r, sqrt(xm_ * xm_ + yc_ * yc_ + zc_ * zc_), nr);
-        double ne_yp = cbet_oracle_interp(c->ne, c->r, sqrt(xc_ * xc_ + yp_ * yp_ + zc_ * zc_), nr);
-        double ne_ym = cbet_oracle_interp(c->ne, c->r, sqrt(xc_ * xc_ + ym_ * ym_ + zc_ * zc_), nr);
-        double ne_zp = cbet_oracle_interp(c->ne, c->r, sqrt(xc_ * xc_ + yc_ * yc_ + zp_ * zp_), nr);
-        double ne_zm = cbet_oracle_interp(c->ne, c->r, sqrt(xc_ * xc_ + yc_ * yc_ + zm_ * zm_), nr);
+        double ne_xp = NODE_NE(ip, cj, ck, sqrt(xp_ * xp_ + yc_ * yc_ + zc_ * zc_));
+        double ne_xm = NODE_NE(im, cj, ck, sqrt(xm_ * xm_ + yc_ * yc_ + zc_ * zc_));
+        double ne_yp = NODE_NE(ci, jp, ck, sqrt(xc_ * xc_ + yp_ * yp_ + zc_ * zc_));
+        double ne_ym = NODE_NE(ci, jm, ck, sqrt(xc_ * xc_ + ym_ * ym_ + zc_ * zc_));
+        double ne_zp = NODE_NE(ci, cj, kp, sqrt(xc_ * xc_ + yc_ * yc_ + zp_ * zp_));
+        double ne_zm = NODE_NE(ci, cj, km, sqrt(xc_ * xc_ + yc_ * yc_ + zm_ * zm_));
 
         /* :268-273 kick, then drift */
         vx -= d->xconst * (ne_xp - ne_xm);
@@ -342,17 +347,26 @@ static int trace_one(const ray_ctx *c, int beam, int pre_raynum)
         }
 
         /* :296-311 inverse-bremsstrahlung absorption at the new node */
-        double rho = sqrt(sq(ci * dx + xmin) + sq(cj * dy + ymin) + sq(ck * dz + zmin));
-        double ed = cbet_oracle_interp(c->ne, c->r, rho, nr);
-        double etemp = cbet_oracle_interp(c->te, c->r, rho, nr);
-        double eta = 5.2e-5 * 10.0 / (etemp * sqrt(etemp));
-        double nuei = (1e6 * ed * sq(K_EC) / K_ME) * eta;
         double inc;
-        if (cfg->absorption == 1) {
-            inc = ed / d->ncrit * nuei * dt * uray;
-            uray -= inc;
+        if (c->kap3d) { /* caller-supplied absorption factor per node (= ed/ncrit*nuei*dt, see node_tables) */
+            if (cfg->absorption == 1) {
+                inc = c->kap3d[((long)ci * ny + cj) * nz + ck] * uray;
+                uray -= inc;
+            } else {
+                inc = uray;
+            }
         } else {
-            inc = uray;
+            double rho = sqrt(sq(ci * dx + xmin) + sq(cj * dy + ymin) + sq(ck * dz + zmin));
+            double ed = cbet_oracle_interp(c->ne, c->r, rho, nr);
+            double etemp = cbet_oracle_interp(c->te, c->r, rho, nr);
+            double eta = 5.2e-5 * 10.0 / (etemp * sqrt(etemp));
+            double nuei = (1e6 * ed * sq(K_EC) / K_ME) * eta;
+            if (cfg->absorption == 1) {
+                inc = ed / d->ncrit * nuei * dt * uray;
+                uray -= inc;
+            } else {
+                inc = uray;
+            }
         }
 
         /* :319-336 offsets from the node and the eight linear weights */
@@ -445,6 +459,31 @@ long long cbet_oracle_trace(const cbet_oracle_config *cfg, const double *beam_no
                 if (id_traced_d(cfg, &c.d, id)) beam_steps += trace_one(&c, beam, id);
         }
         if (steps_per_beam) steps_per_beam[beam] = beam_steps;
+        total += beam_steps;
+    }
+    return total;
+}
+
+/* Trace with caller-supplied node tables ne3d / kap3d[nx*ny*nz] instead of radial profiles: the
+ * checker for the product's 3-D plasma entry (cbet_trace_nodes).  Same ray loop as above. */
+long long cbet_oracle_trace_tables(const cbet_oracle_config *cfg, const double *beam_norm,
+                                   const double *ne3d, const double *kap3d, int beam_lo, int beam_hi,
+                                   double *edep, int nthreads)
+{
+    static double phase_r[CBET_ORACLE_NPHASE], pow_r[CBET_ORACLE_NPHASE];
+    ray_ctx c;
+    ctx_init(&c, cfg, beam_norm, NULL, NULL, NULL, phase_r, pow_r, edep, nthreads > 1);
+    c.ne3d = ne3d;
+    c.kap3d = kap3d;
+    const int nrays = c.d.nrays;
+    long long total = 0;
+    for (int beam = beam_lo; beam < beam_hi; ++beam) {
+        long long beam_steps = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads > 1 ? nthreads : 1) reduction(+ : beam_steps)
+#endif
+        for (int id = 0; id < nrays; ++id)
+            if (id_traced_d(cfg, &c.d, id)) beam_steps += trace_one(&c, beam, id);
         total += beam_steps;
     }
     return total;

@@ -92,6 +92,12 @@ long long cbet_oracle_trace(const cbet_oracle_config *cfg, const double *beam_no
                             int beam_lo, int beam_hi, double *edep, int nthreads,
                             long long *steps_per_beam);
 
+/* Same ray loop, but node values come from caller-supplied tables ne3d / kap3d[nx*ny*nz] (an
+ * arbitrary, not necessarily spherical, plasma) -- the checker for cbet_trace_nodes. */
+long long cbet_oracle_trace_tables(const cbet_oracle_config *cfg, const double *beam_norm,
+                                   const double *ne3d, const double *kap3d, int beam_lo, int beam_hi,
+                                   double *edep, int nthreads);
+
 /* Same, for an explicit list of (beam, ray id) pairs -- used by the sharding tests. */
 long long cbet_oracle_trace_list(const cbet_oracle_config *cfg, const double *beam_norm,
                                  const double *r_prof, const double *ne_prof,

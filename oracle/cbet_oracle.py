@@ -76,6 +76,8 @@ def lib():
     L.cbet_oracle_trace.argtypes = [C.POINTER(Config), _dp, _dp, _dp, _dp, C.c_int, C.c_int, _dp,
                                     C.c_int, C.c_void_p]
     L.cbet_oracle_trace.restype = C.c_longlong
+    L.cbet_oracle_trace_tables.argtypes = [C.POINTER(Config), _dp, _dp, _dp, C.c_int, C.c_int, _dp, C.c_int]
+    L.cbet_oracle_trace_tables.restype = C.c_longlong
     L.cbet_oracle_trace_list.argtypes = [C.POINTER(Config), _dp, _dp, _dp, _dp, C.c_long, _ip, _ip,
                                          _dp, C.c_int]
     L.cbet_oracle_trace_list.restype = C.c_longlong
@@ -149,6 +151,18 @@ def trace(cfg, beam_norm, r, ne, te, beam_lo=0, beam_hi=None, nthreads=1, edep=N
                                     per_beam.ctypes.data_as(C.c_void_p))
     if want_per_beam:
         return edep, int(steps), per_beam
+    return edep, int(steps)
+
+
+def trace_tables(cfg, beam_norm, ne3d, kap3d, beam_lo=0, beam_hi=None, nthreads=1):
+    """Trace with caller-supplied node tables (3-D plasma).  Returns (edep, ray_steps)."""
+    if beam_hi is None:
+        beam_hi = cfg.nbeams
+    edep = np.zeros(grid_shape(cfg))
+    steps = lib().cbet_oracle_trace_tables(C.byref(cfg), np.ascontiguousarray(beam_norm, dtype=np.float64),
+                                           np.ascontiguousarray(ne3d, dtype=np.float64),
+                                           np.ascontiguousarray(kap3d, dtype=np.float64), beam_lo, beam_hi,
+                                           edep, nthreads)
     return edep, int(steps)
 
 

@@ -514,3 +514,35 @@ def test_beam_resolved_deposition(api, oracle, inputs, torch_cuda, variant):
     part = part.cpu().numpy()
     assert float(np.abs(part[[0, 3, 4]]).sum()) == 0.0 and part[1].sum() > 0 and part[2].sum() > 0
     tr.close()
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_non_spherical_plasma_against_table_oracle(api, oracle, inputs, torch_cuda, variant):
+    """SURVEY 8(f) f3 with a genuinely 3-D plasma: an l=2-style density perturbation and an off-centre
+    absorbing blob.  The oracle's node-table tracer is the checker (same ray loop as the pinned
+    radial path, node values looked up instead of interpolated)."""
+    bn, r, ne, te = inputs
+    n, beams = 48, [1, 16, 29, 38, 47, 55]
+    cfg = oracle.default_config(n, nbeams=len(beams))
+    ne3d, kap = oracle.node_tables(cfg, r, ne, te)
+    ax = np.linspace(-0.13, 0.13, n)
+    X, Y, Z = np.meshgrid(ax, ax, ax, indexing="ij")
+    R2 = X * X + Y * Y + Z * Z + 1e-30
+    ne3d = ne3d * (1.0 + 0.15 * (3.0 * Z * Z / R2 - 1.0) * 0.5 + 0.05 * X * Y / R2)
+    kap = kap * (1.0 + 2.0 * np.exp(-((X - 0.05) ** 2 + (Y + 0.04) ** 2 + Z ** 2) / 0.02 ** 2))
+    oe, osteps = oracle.trace_tables(cfg, bn[beams].copy(), ne3d, kap, nthreads=NCPU)
+    tr = make_tracer(api, inputs, n, beams=beams)
+    d = tr.derived
+    d_ne, d_kap = torch_cuda.from_numpy(ne3d).cuda(), torch_cuda.from_numpy(kap).cuda()
+    e = tr.new_grid()
+    tr.counters(reset=True)
+    api.trace_nodes(0, d.nindices, d_ne, d_kap, e, tr.d_bbeam_norm, tr.d_beam_norm, tr.d_pow_r, tr.d_phase_r,
+                    d.xconst, d.yconst, d.zconst,
+                    tr.params.copy(beam_lo=0, beam_hi=len(beams), kernel_variant=variant), tr.ctx,
+                    torch_cuda.cuda.current_stream().cuda_stream)
+    c = tr.counters(reset=True)
+    assert c.ray_steps == osteps
+    assert parity_err(e.cpu().numpy(), oe) < PARITY_TOL
+    sph, _ = run(tr, torch_cuda, kernel_variant=variant)       # the spherical plasma differs visibly
+    assert parity_err(sph, oe) > 1e-3
+    tr.close()

@@ -227,3 +227,14 @@ def test_config1_uniform_plasma_properties(oracle, inputs, golden):
         pth = oracle.ray_path(cfg, bn2, r, ne_u, te_u, 1, ray)
         e1, s1 = oracle.trace_list(cfg, bn2, r, ne_u, te_u, [1], [ray])
         assert s1 == len(pth) and e1.sum() == pytest.approx(pth[:, 6].sum(), rel=1e-13)
+
+
+def test_table_tracer_equals_radial_tracer(oracle, inputs):
+    """The oracle's node-table path (checker for the 3-D plasma entry) is the same ray loop: fed the
+    tabulated radial profile it must reproduce the pinned radial path -- same steps, same grid."""
+    bn, r, ne, te = inputs
+    cfg = oracle.default_config(40, nbeams=6)
+    e1, s1 = oracle.trace(cfg, bn[:6].copy(), r, ne, te, nthreads=NCPU)
+    ne3d, kap = oracle.node_tables(cfg, r, ne, te)
+    e2, s2 = oracle.trace_tables(cfg, bn[:6].copy(), ne3d, kap, nthreads=NCPU)
+    assert s1 == s2 and parity_err(e2, e1) < 1e-12
