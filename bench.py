@@ -31,9 +31,16 @@ def cpu_baseline(n, r, ne, te, bn):
     t0 = time.perf_counter()
     _, steps = O.trace(cfg, bn, r, ne, te, beam_lo=0, beam_hi=nb, nthreads=1)
     dt = time.perf_counter() - t0
+    ncores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    t0 = time.perf_counter()
+    _, steps_mt = O.trace(cfg, bn, r, ne, te, beam_lo=0, beam_hi=nb, nthreads=ncores)
+    dt_mt = time.perf_counter() - t0
     return {"value": steps / dt, "unit": "ray-steps/s", "cores": 1, "kind": "port",
             "sample": "beams 0-%d of the %d^3 60-beam s83177 sweep: %d ray-steps in %.1f s, "
-                      "serial ray loop, 1 thread, gcc -O2 -ffp-contract=off" % (nb - 1, n, steps, dt)}
+                      "serial ray loop, 1 thread, gcc -O2 -ffp-contract=off" % (nb - 1, n, steps, dt),
+            # BASELINE.md section 3's second figure: the same sample on every host core (OpenMP over rays)
+            "all_cores_value": steps_mt / dt_mt, "all_cores": ncores,
+            "all_cores_note": "threads capped at 16, the CPU share of a 1-GPU job on this pool"}
 
 
 def measured_traffic(workload, variant):
