@@ -546,3 +546,40 @@ def test_non_spherical_plasma_against_table_oracle(api, oracle, inputs, torch_cu
     sph, _ = run(tr, torch_cuda, kernel_variant=variant)       # the spherical plasma differs visibly
     assert parity_err(sph, oe) > 1e-3
     tr.close()
+
+
+def test_pass_is_hip_graph_capturable(api, oracle, inputs, torch_cuda):
+    """A launch allocates nothing and never synchronises once its workspace exists, so zero +
+    tabulate + trace can be captured in a HIP graph (torch.cuda.CUDAGraph) and replayed; the replay
+    deposits what the eager launch deposits and what the oracle does."""
+    bn, r, ne, te = inputs
+    n, beams = 32, list(range(0, 60, 12))
+    tr = make_tracer(api, inputs, n, beams=beams)
+    e = tr.new_grid()
+
+    def one_pass():
+        e.zero_()
+        tr.launch(e)
+
+    one_pass()
+    torch_cuda.cuda.synchronize()
+    eager = e.clone()
+    side = torch_cuda.cuda.Stream()
+    side.wait_stream(torch_cuda.cuda.current_stream())
+    with torch_cuda.cuda.stream(side):
+        one_pass()
+        graph = torch_cuda.cuda.CUDAGraph()
+        with torch_cuda.cuda.graph(graph, stream=side):
+            one_pass()
+    torch_cuda.cuda.current_stream().wait_stream(side)
+    torch_cuda.cuda.synchronize()
+    for _ in range(3):
+        e.fill_(-1.0)
+        graph.replay()
+    torch_cuda.cuda.synchronize()
+    cfg = oracle.default_config(n, nbeams=len(beams))
+    oe, _ = oracle.trace(cfg, bn[beams].copy(), r, ne, te, nthreads=NCPU)
+    assert parity_err(e.cpu().numpy(), eager.cpu().numpy()) < PARITY_TOL
+    assert parity_err(e.cpu().numpy(), oe) < PARITY_TOL
+    del graph
+    tr.close()
