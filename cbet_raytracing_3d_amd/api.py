@@ -81,6 +81,28 @@ class Counters(C.Structure):
     ]
 
 
+MAX_CBET_BEAMS = 64
+
+
+class GainParams(C.Structure):
+    """cbet_gain_params -- the CBET stage (parity unpinned: no reference counterpart)."""
+    _fields_ = [
+        ("z_ion", C.c_double), ("te_ev", C.c_double), ("ti_ev", C.c_double), ("mi_over_me", C.c_double),
+        ("iaw", C.c_double),
+        ("mach_r0", C.c_double), ("mach_0", C.c_double), ("mach_r1", C.c_double), ("mach_1", C.c_double),
+        ("max_exponent", C.c_double), ("relax", C.c_double), ("tolerance", C.c_double),
+        ("max_passes", C.c_int), ("reserved_", C.c_int),
+    ]
+
+
+class CbetReport(C.Structure):
+    _fields_ = [
+        ("passes", C.c_int), ("converged", C.c_int), ("change", C.c_double), ("imbalance", C.c_double),
+        ("beam_gain", C.c_double * MAX_CBET_BEAMS),
+        ("ray_steps", C.c_ulonglong), ("ray_steps_final", C.c_ulonglong),
+    ]
+
+
 # Every symbol include/cbet_mi355x.h declares; tests check the library exports all of them.
 EXPORTS = [
     "cbet_last_error", "cbet_version", "cbet_params_default", "cbet_derive",
@@ -89,6 +111,8 @@ EXPORTS = [
     "cbet_context_create", "cbet_context_destroy", "cbet_context_counters", "cbet_context_tables",
     "cbet_launch_ray_XYZ", "cbet_tabulate_plasma", "cbet_trace_nodes", "cbet_ray_tracing",
     "cbet_write_text", "cbet_edep_average", "cbet_debug_bounds_violations",
+    "cbet_gain_params_default", "cbet_gain_constants", "cbet_trace_cbet", "cbet_gain_field",
+    "cbet_cbet_workspace_bytes", "cbet_cbet_solve",
 ]
 
 _lib = None
@@ -139,6 +163,15 @@ def lib():
     L.cbet_write_text.argtypes = [dp, C.c_int, C.c_int, C.c_int, C.c_char_p]
     L.cbet_write_text.restype = C.c_longlong
     L.cbet_edep_average.argtypes = [dp, dp, C.c_int, C.c_int, C.c_int]
+    L.cbet_gain_params_default.argtypes = [C.POINTER(GainParams)]
+    L.cbet_gain_constants.argtypes = [C.POINTER(Params), C.POINTER(GainParams), dp, dp, dp]
+    L.cbet_trace_cbet.argtypes = [C.c_int, C.c_uint, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp,
+                                  C.c_double, C.c_double, C.c_double, C.POINTER(Params), C.POINTER(GainParams), vp, vp]
+    L.cbet_gain_field.argtypes = [vp, vp, vp, vp, C.POINTER(Params), C.POINTER(GainParams), vp, vp]
+    L.cbet_cbet_workspace_bytes.argtypes = [C.POINTER(Params)]
+    L.cbet_cbet_workspace_bytes.restype = C.c_size_t
+    L.cbet_cbet_solve.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(Params), C.POINTER(GainParams), vp, vp, vp,
+                                  C.POINTER(CbetReport)]
     for name in EXPORTS:
         getattr(L, name)  # AttributeError here = the library is older than the header
     _lib = L
@@ -332,6 +365,49 @@ def trace_nodes(b, nindices, ne3d, kappa3d, edep, bbeam_norm, beam_norm, pow_r, 
         b, nindices, _addr(ne3d), _addr(kappa3d), _addr(edep), _addr(bbeam_norm), _addr(beam_norm),
         _addr(pow_r), _addr(phase_r), xconst, yconst, zconst, C.byref(params), ctx.handle,
         _addr(stream)))
+
+
+# ---- CBET stage (parity unpinned) -----------------------------------------------
+def default_gain_params(**overrides):
+    g = GainParams()
+    _check(lib().cbet_gain_params_default(C.byref(g)))
+    for k, v in overrides.items():
+        setattr(g, k, v)
+    return g
+
+
+def gain_constants(params, gain_params):
+    """(constant1, cs, gain_const) of def.cuh:111, 113."""
+    out = [C.c_double() for _ in range(3)]
+    _check(lib().cbet_gain_constants(C.byref(params), C.byref(gain_params), *[C.byref(o) for o in out]))
+    return tuple(o.value for o in out)
+
+
+def trace_cbet(b, nindices, ne3d, kappa3d, gain, quantity, out, beam_gain, bbeam_norm, beam_norm, pow_r,
+               phase_r, xconst, yconst, zconst, params, gain_params, ctx, stream=None):
+    _check(lib().cbet_trace_cbet(
+        b, nindices, _addr(ne3d), _addr(kappa3d), _addr(gain), quantity, _addr(out), _addr(beam_gain),
+        _addr(bbeam_norm), _addr(beam_norm), _addr(pow_r), _addr(phase_r), xconst, yconst, zconst,
+        C.byref(params), C.byref(gain_params), ctx.handle, _addr(stream)))
+
+
+def gain_field(fields, ne3d, gain, change, params, gain_params, ctx, stream=None):
+    _check(lib().cbet_gain_field(_addr(fields), _addr(ne3d), _addr(gain), _addr(change), C.byref(params),
+                                 C.byref(gain_params), ctx.handle, _addr(stream)))
+
+
+def cbet_workspace_bytes(params):
+    return int(lib().cbet_cbet_workspace_bytes(C.byref(params)))
+
+
+def cbet_solve(te_data_g, r_data_g, ne_data_g, edep, bbeam_norm, beam_norm, pow_r, phase_r, params,
+               gain_params, workspace=None, ctx=None, stream=None):
+    rep = CbetReport()
+    _check(lib().cbet_cbet_solve(_addr(te_data_g), _addr(r_data_g), _addr(ne_data_g), _addr(edep),
+                                 _addr(bbeam_norm), _addr(beam_norm), _addr(pow_r), _addr(phase_r),
+                                 C.byref(params), C.byref(gain_params), _addr(workspace),
+                                 ctx.handle if ctx is not None else None, _addr(stream), C.byref(rep)))
+    return rep
 
 
 def ray_tracing(te_profile, r_profile, ne_profile, edep, params, beam_norm=None, gpus=None, ngpu=1):

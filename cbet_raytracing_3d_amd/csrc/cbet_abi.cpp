@@ -497,10 +497,19 @@ int cbet_tabulate_plasma(cbet_context *ctx, const cbet_params *p, const double *
     return CBET_OK;
 }
 
-int cbet_trace_nodes(int b, unsigned nindices, const double *ne3d, const double *kappa3d,
-                     double *edep, const double *bbeam_norm, const double *beam_norm,
-                     const double *pow_r, const double *phase_r, double xconst, double yconst,
-                     double zconst, const cbet_params *p, cbet_context *ctx, void *stream)
+// CBET hooks of a trace launch (all zero: the reference path).
+struct CbetHooks {
+    const double *gain = nullptr;
+    int quantity = 0;
+    double *beam_gain = nullptr;
+    double max_exponent = 0.0;
+};
+
+static int trace_impl(int b, unsigned nindices, const double *ne3d, const double *kappa3d,
+                      double *edep, const double *bbeam_norm, const double *beam_norm,
+                      const double *pow_r, const double *phase_r, double xconst, double yconst,
+                      double zconst, const cbet_params *p, cbet_context *ctx, void *stream,
+                      const CbetHooks &hooks)
 {
     if (!ctx) return fail(CBET_EINVAL, "NULL context");
     if (int rc = validate(p)) return rc;
@@ -539,6 +548,9 @@ int cbet_trace_nodes(int b, unsigned nindices, const double *ne3d, const double 
     if (pre > 2) return fail(CBET_EINVAL, "lds_prereduce must be -1 (auto) or 0..2");
     if (two && (rl != 0 || pre != 0 || wl != 3 || p->lds_corner_flip == 0))
         return fail(CBET_EINVAL, "lds_two_boxes needs lds_window_log2=3, one copy, no pre-reduction, corner flip on");
+    const bool cbet_hooks = hooks.gain || hooks.quantity != 0 || hooks.beam_gain;
+    if (cbet_hooks && !(variant == CBET_KERNEL_LDS_WINDOW && two))
+        return fail(CBET_EINVAL, "the CBET hooks exist for the default kernel configuration only");
 
     const cbet_derived &d = ctx->d;
     TraceArgs a{};
@@ -576,6 +588,8 @@ int cbet_trace_nodes(int b, unsigned nindices, const double *ne3d, const double 
     a.edep = edep;
     a.grid_stride = p->per_beam_grids ? d.edep_size : 0;
     a.counters = ctx->counters;
+    a.gain = hooks.gain; a.hsize = d.edep_size; a.quantity = hooks.quantity;
+    a.max_exponent = hooks.max_exponent; a.beam_gain = hooks.beam_gain;
     a.timeline = nullptr;
 #ifdef CBET_EXPERIMENT_TIMELINE
     {   // diagnostic builds: the caller passes a device buffer of 3 x workgroups u64 through the environment
@@ -589,6 +603,15 @@ int cbet_trace_nodes(int b, unsigned nindices, const double *ne3d, const double 
     const bool flip = p->lds_corner_flip != 0;  // auto: on
     CBET_HIP(launch_trace(a, variant, wl, rl, pre, flip, two, p->force_wide_index != 0, (hipStream_t)stream));
     return CBET_OK;
+}
+
+int cbet_trace_nodes(int b, unsigned nindices, const double *ne3d, const double *kappa3d,
+                     double *edep, const double *bbeam_norm, const double *beam_norm,
+                     const double *pow_r, const double *phase_r, double xconst, double yconst,
+                     double zconst, const cbet_params *p, cbet_context *ctx, void *stream)
+{
+    return trace_impl(b, nindices, ne3d, kappa3d, edep, bbeam_norm, beam_norm, pow_r, phase_r, xconst, yconst,
+                      zconst, p, ctx, stream, CbetHooks{});
 }
 
 // One lazily created workspace per device for callers that pass ctx == NULL (the reference's
@@ -629,6 +652,191 @@ int cbet_launch_ray_XYZ(int b, unsigned nindices, double *te_data_g, double *r_d
     if (int rc = cbet_tabulate_plasma(ctx, p, te_data_g, r_data_g, ne_data_g, stream)) return rc;
     return cbet_trace_nodes(b, nindices, nullptr, nullptr, edep, bbeam_norm, beam_norm, pow_r, phase_r,
                             xconst, yconst, zconst, p, ctx, stream);
+}
+
+// ---- CBET stage (parity unpinned -- see the header) ---------------------------
+static int validate_gain(const cbet_params *p, const cbet_gain_params *g)
+{
+    if (!g) return fail(CBET_EINVAL, "gain params is NULL");
+    if (p->nbeams > CBET_MAX_CBET_BEAMS) return fail(CBET_EINVAL, "the CBET stage supports at most %d beams", CBET_MAX_CBET_BEAMS);
+    if (!(g->max_exponent > 0.0 && g->max_exponent <= 1.0)) return fail(CBET_EINVAL, "max_exponent must be in (0, 1]");
+    if (!(g->relax > 0.0 && g->relax <= 1.0)) return fail(CBET_EINVAL, "relax must be in (0, 1]");
+    if (!(g->iaw > 0.0) || !(g->z_ion > 0.0) || !(g->te_ev > 0.0) || !(g->ti_ev >= 0.0) || !(g->mi_over_me > 0.0))
+        return fail(CBET_EINVAL, "bad plasma constants in gain params");
+    if (!(g->mach_r1 > g->mach_r0)) return fail(CBET_EINVAL, "mach_r1 must exceed mach_r0");
+    return CBET_OK;
+}
+
+int cbet_gain_params_default(cbet_gain_params *g)
+{
+    if (!g) return fail(CBET_EINVAL, "gain params is NULL");
+    std::memset(g, 0, sizeof *g);
+    g->z_ion = 3.1;           // def.cuh:100
+    g->te_ev = 2.0e3;         // def.cuh:104
+    g->ti_ev = 1.0e3;         // def.cuh:106
+    g->mi_over_me = 10230.0;  // def.cuh:101-102
+    g->iaw = 0.2;             // def.cuh:107
+    g->mach_r0 = 0.04; g->mach_0 = 0.4;   // def.cuh:114 names an undefined `machnum`; a radial ramp stands in
+    g->mach_r1 = 0.13; g->mach_1 = 2.4;
+    g->max_exponent = 1.0;
+    g->relax = 1.0;
+    g->tolerance = 1e-4;
+    g->max_passes = 12;
+    return CBET_OK;
+}
+
+int cbet_gain_constants(const cbet_params *p, const cbet_gain_params *g, double *constant1, double *cs,
+                        double *gain_const)
+{
+    if (int rc = validate(p)) return rc;
+    if (int rc = validate_gain(p, g)) return rc;
+    cbet_derived d;
+    derive_core(p, &d);
+    const double estat = 4.80320427e-10;            // def.cuh:98
+    const double kb = 1.3806485279e-16;             // def.cuh:108
+    const double te_k = g->te_ev * 11604.5052;      // def.cuh:103
+    const double ti_k = g->ti_ev * 11604.5052;      // def.cuh:105
+    const double mi_kg = g->mi_over_me * kMe;       // def.cuh:102
+    const double c1 = (std::pow(estat, 2)) / (4 * (1.0e3 * kMe) * kC * d.omega * kb * te_k * (1 + 3 * ti_k / (g->z_ion * te_k)));  // def.cuh:111
+    const double sound = 1e2 * std::sqrt(kEc * (g->z_ion * g->te_ev + 3.0 * g->ti_ev) / mi_kg);                                   // def.cuh:113
+    if (constant1) *constant1 = c1;
+    if (cs) *cs = sound;
+    if (gain_const) *gain_const = c1 * (8.0 * M_PI * 1.0e7 / kC);  // |E|^2 = 8 pi 1e7 I / c
+    return CBET_OK;
+}
+
+int cbet_trace_cbet(int b, unsigned nindices, const double *ne3d, const double *kappa3d,
+                    const double *gain, int quantity, double *out, double *beam_gain,
+                    const double *bbeam_norm, const double *beam_norm, const double *pow_r,
+                    const double *phase_r, double xconst, double yconst, double zconst,
+                    const cbet_params *p, const cbet_gain_params *g, cbet_context *ctx, void *stream)
+{
+    if (int rc = validate(p)) return rc;
+    if (int rc = validate_gain(p, g)) return rc;
+    if (quantity < 0 || quantity > 4) return fail(CBET_EINVAL, "quantity must be 0..4");
+    CbetHooks h;
+    h.gain = gain; h.quantity = quantity; h.beam_gain = beam_gain; h.max_exponent = g->max_exponent;
+    return trace_impl(b, nindices, ne3d, kappa3d, out, bbeam_norm, beam_norm, pow_r, phase_r, xconst, yconst, zconst,
+                      p, ctx, stream, h);
+}
+
+int cbet_gain_field(double *fields, const double *ne3d, double *gain, double *change,
+                    const cbet_params *p, const cbet_gain_params *g, cbet_context *ctx, void *stream)
+{
+    if (!ctx) return fail(CBET_EINVAL, "NULL context");
+    if (int rc = validate(p)) return rc;
+    if (int rc = check_geometry(ctx, p)) return rc;
+    if (int rc = validate_gain(p, g)) return rc;
+    if (!fields || !gain) return fail(CBET_EINVAL, "NULL device pointer");
+    double cs = 0, gc = 0;
+    if (int rc = cbet_gain_constants(p, g, nullptr, &cs, &gc)) return rc;
+    const cbet_derived &d = ctx->d;
+    GainArgs a{};
+    a.nx = p->nx; a.ny = p->ny; a.nz = p->nz; a.nbeams = p->nbeams;
+    a.xmin = p->xmin; a.ymin = p->ymin; a.zmin = p->zmin;
+    a.dx = d.dx; a.dy = d.dy; a.dz = d.dz; a.dt = d.dt;
+    a.ncrit = d.ncrit; a.k0 = d.omega / kC;
+    a.cs = cs; a.gain_const = gc; a.iaw = g->iaw;
+    a.mach_r0 = g->mach_r0; a.mach_0 = g->mach_0; a.mach_r1 = g->mach_r1; a.mach_1 = g->mach_1;
+    a.relax = g->relax;
+    a.fields = fields; a.ne3d = ne3d ? ne3d : ctx->ne3d; a.gain = gain; a.change = change;
+    DeviceGuard guard;
+    CBET_HIP(hipSetDevice(ctx->gpu));
+    CBET_HIP(launch_field_normalize(a, (hipStream_t)stream));
+    CBET_HIP(launch_gain_field(a, (hipStream_t)stream));
+    return CBET_OK;
+}
+
+size_t cbet_cbet_workspace_bytes(const cbet_params *p)
+{
+    if (!p || validate(p) != CBET_OK) return 0;
+    const size_t hsize = (size_t)(p->nx + 2) * (p->ny + 2) * (p->nz + 2);
+    return (5 * (size_t)p->nbeams * hsize + 2 + CBET_MAX_CBET_BEAMS) * sizeof(double);
+}
+
+int cbet_cbet_solve(double *te_data_g, double *r_data_g, double *ne_data_g, double *edep,
+                    double *bbeam_norm, double *beam_norm, double *pow_r, double *phase_r,
+                    const cbet_params *p, const cbet_gain_params *g, void *workspace,
+                    cbet_context *ctx, void *stream, cbet_cbet_report *report)
+{
+    if (int rc = validate(p)) return rc;
+    if (int rc = validate_gain(p, g)) return rc;
+    if (p->shard_count > 1) return fail(CBET_EINVAL, "cbet_cbet_solve runs on one device; the sharded loop is tracer.cbet_solve");
+    if (g->max_passes < 1) return fail(CBET_EINVAL, "max_passes must be >= 1");
+    if (!edep || !beam_norm || !pow_r || !phase_r) return fail(CBET_EINVAL, "NULL device pointer");
+    if (!ctx) {
+        if (int rc = default_context(p, &ctx)) return rc;
+    }
+    if (int rc = check_geometry(ctx, p)) return rc;
+    const cbet_derived &d = ctx->d;
+    hipStream_t s = (hipStream_t)stream;
+    DeviceGuard guard;
+    CBET_HIP(hipSetDevice(ctx->gpu));
+
+    const size_t hsize = (size_t)d.edep_size, nb = (size_t)p->nbeams;
+    const size_t bytes = cbet_cbet_workspace_bytes(p);
+    double *ws = (double *)workspace;
+    bool own = false;
+    if (!ws) {
+        hipError_t e = hipMalloc((void **)&ws, bytes);
+        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? CBET_ENOMEM : CBET_EHIP, "hipMalloc(cbet workspace, %zu bytes): %s", bytes, hipGetErrorString(e));
+        own = true;
+    }
+    double *fields = ws, *gain = ws + 4 * nb * hsize, *change = gain + nb * hsize, *beam_gain = change + 2;
+    int rc = CBET_OK;
+    cbet_counters c0{}, c1{};
+    cbet_cbet_report rep{};
+    auto body = [&]() -> int {
+        if (int r = cbet_tabulate_plasma(ctx, p, te_data_g, r_data_g, ne_data_g, stream)) return r;
+        if (int r = cbet_context_counters(ctx, stream, &c0, 0)) return r;
+        CBET_HIP(hipMemsetAsync(gain, 0, nb * hsize * sizeof(double), s));
+        cbet_params pf = *p;            // field passes: beam-resolved grids, every beam
+        pf.per_beam_grids = 1; pf.beam_lo = 0; pf.beam_hi = p->nbeams;
+        cbet_params pd = *p;            // deposition pass: the caller's grid layout, every beam
+        pd.beam_lo = 0; pd.beam_hi = p->nbeams;
+        for (int pass = 0; pass < g->max_passes; ++pass) {
+            CBET_HIP(hipMemsetAsync(fields, 0, 4 * nb * hsize * sizeof(double), s));
+            for (int q = 1; q <= 4; ++q) {
+                CbetHooks h;
+                h.gain = pass == 0 ? nullptr : gain; h.quantity = q; h.max_exponent = g->max_exponent;
+                if (int r = trace_impl(0, (unsigned)d.nindices, nullptr, nullptr, fields + (size_t)(q - 1) * nb * hsize, bbeam_norm,
+                                       beam_norm, pow_r, phase_r, d.xconst, d.yconst, d.zconst, &pf, ctx, stream, h))
+                    return r;
+            }
+            CBET_HIP(hipMemsetAsync(change, 0, 2 * sizeof(double), s));
+            if (int r = cbet_gain_field(fields, nullptr, gain, change, p, g, ctx, stream)) return r;
+            double hc[2];
+            CBET_HIP(hipMemcpyAsync(hc, change, sizeof hc, hipMemcpyDeviceToHost, s));
+            CBET_HIP(hipStreamSynchronize(s));
+            rep.passes = pass + 1;
+            rep.change = hc[1] > 0.0 ? hc[0] / hc[1] : 0.0;
+            if (rep.change < g->tolerance) { rep.converged = 1; break; }
+        }
+        CBET_HIP(hipMemsetAsync(beam_gain, 0, CBET_MAX_CBET_BEAMS * sizeof(double), s));
+        if (int r = cbet_context_counters(ctx, stream, &c1, 0)) return r;
+        rep.ray_steps = c1.ray_steps - c0.ray_steps;
+        CbetHooks h;
+        h.gain = gain; h.quantity = 0; h.beam_gain = beam_gain; h.max_exponent = g->max_exponent;
+        if (int r = trace_impl(0, (unsigned)d.nindices, nullptr, nullptr, edep, bbeam_norm, beam_norm, pow_r, phase_r,
+                               d.xconst, d.yconst, d.zconst, &pd, ctx, stream, h))
+            return r;
+        CBET_HIP(hipMemcpyAsync(rep.beam_gain, beam_gain, nb * sizeof(double), hipMemcpyDeviceToHost, s));
+        cbet_counters c2{};
+        if (int r = cbet_context_counters(ctx, stream, &c2, 0)) return r;   // synchronises
+        rep.ray_steps_final = c2.ray_steps - c1.ray_steps;
+        rep.ray_steps += rep.ray_steps_final;
+        double net = 0.0, mag = 0.0;
+        for (size_t bb = 0; bb < nb; ++bb) { net += rep.beam_gain[bb]; mag += std::fabs(rep.beam_gain[bb]); }
+        rep.imbalance = mag > 0.0 ? std::fabs(net) / mag : 0.0;
+        return CBET_OK;
+    };
+    rc = body();
+    if (own) {
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(ws);
+    }
+    if (rc == CBET_OK && report) *report = rep;
+    return rc;
 }
 
 }  // extern "C"

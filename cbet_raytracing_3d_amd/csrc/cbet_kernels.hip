@@ -522,7 +522,34 @@ __device__ __forceinline__ double node_load(const double *base, unsigned idx)
 //   IDX64    : node tables of >= 2^32 bytes (n > 812)
 //   ABSORB   : def.cuh:118 absorption == 1 (false: bookkeeping mode, launch_ray_XZ.cu:307-311)
 // ---------------------------------------------------------------------------------------------
-template <int DEPOSIT, int WL, int RL, int PRE, bool FLIP, bool TWOBOX, bool IDX64, bool ABSORB>
+// phi(x) = (exp(x) - 1) / x, |x| <= 1: degree-17 Horner polynomial of plain multiplies and adds, the
+// operation sequence the CPU checker of the CBET stage evaluates.  CBET extension only.
+__device__ __forceinline__ double phi_det(double x)
+{
+    double p = 1.0 / 6402373705728000.0;
+    p = p * x + 1.0 / 355687428096000.0;
+    p = p * x + 1.0 / 20922789888000.0;
+    p = p * x + 1.0 / 1307674368000.0;
+    p = p * x + 1.0 / 87178291200.0;
+    p = p * x + 1.0 / 6227020800.0;
+    p = p * x + 1.0 / 479001600.0;
+    p = p * x + 1.0 / 39916800.0;
+    p = p * x + 1.0 / 3628800.0;
+    p = p * x + 1.0 / 362880.0;
+    p = p * x + 1.0 / 40320.0;
+    p = p * x + 1.0 / 5040.0;
+    p = p * x + 1.0 / 720.0;
+    p = p * x + 1.0 / 120.0;
+    p = p * x + 1.0 / 24.0;
+    p = p * x + 1.0 / 6.0;
+    p = p * x + 0.5;
+    p = p * x + 1.0;
+    return p;
+}
+
+// CBET = true adds the cross-beam-energy-transfer hooks (no reference counterpart):
+// gain gathered from the eight deposit nodes, ray energy x exp(K ds), selectable deposited quantity.
+template <int DEPOSIT, int WL, int RL, int PRE, bool FLIP, bool TWOBOX, bool IDX64, bool ABSORB, bool CBET = false>
 __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
 {
     constexpr int NSLOT = (DEPOSIT == 3) ? (TWOBOX ? 2 : 1) * MovingWindow<WL, RL>::NDOUBLES
@@ -649,6 +676,9 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
         }
     };
     if (alive) gather_stencil();
+    const double *const gk = CBET && a.gain ? a.gain + (long)beam * a.hsize : nullptr;  // this beam's gain grid
+    double gained = 0.0;                     // CBET: energy this lane's ray gained
+    double q_dep = 0.0;                      // CBET: the field quantity this step deposits
     double dv0 = 0.0, dv1 = 0.0, dv2 = 0.0;  // deferred slab sums (one per axis) and their nodes
     int dn0 = 0, dn1 = 0, dn2 = 0;
     unsigned slabs_seen = 0;                 // wave-uniform: value of the slab counter when last drained
@@ -773,6 +803,35 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
             wgt[5] = zy01 * Fx1;
             wgt[6] = zy11 * Fx0;
             wgt[7] = zy11 * Fx1;
+            if (CBET) {
+                // path length of the step; u_eff = the ray's energy averaged over the step
+                double ds = 0.0;
+                if (gk || a.quantity == 1) ds = sqrt(s.vx * s.vx + s.vy * s.vy + s.vz * s.vz) * a.dt;
+                double u_eff = s.uray;
+                if (gk) {
+                    // K at the eight deposit nodes, weighted like the deposit.  The pairwise tree makes the
+                    // sum independent of the corner order (FLIP swaps operands of commutative adds only).
+                    const int nX0 = __mul24(X0, sXh), nX1 = __mul24(X1, sXh), nY0 = __mul24(Y0, sYh), nY1 = __mul24(Y1, sYh);
+                    const double g0 = node_load<IDX64>(gk, (unsigned)(nX0 + nY0 + Z0)), g1 = node_load<IDX64>(gk, (unsigned)(nX1 + nY0 + Z0));
+                    const double g2 = node_load<IDX64>(gk, (unsigned)(nX0 + nY0 + Z1)), g3 = node_load<IDX64>(gk, (unsigned)(nX1 + nY0 + Z1));
+                    const double g4 = node_load<IDX64>(gk, (unsigned)(nX0 + nY1 + Z0)), g5 = node_load<IDX64>(gk, (unsigned)(nX1 + nY1 + Z0));
+                    const double g6 = node_load<IDX64>(gk, (unsigned)(nX0 + nY1 + Z1)), g7 = node_load<IDX64>(gk, (unsigned)(nX1 + nY1 + Z1));
+                    const double k01 = wgt[0] * g0 + wgt[1] * g1, k23 = wgt[2] * g2 + wgt[3] * g3;
+                    const double k45 = wgt[4] * g4 + wgt[5] * g5, k67 = wgt[6] * g6 + wgt[7] * g7;
+                    double x = ((k01 + k23) + (k45 + k67)) * ds;
+                    if (x > a.max_exponent) x = a.max_exponent;
+                    if (x < -a.max_exponent) x = -a.max_exponent;
+                    const double phi = phi_det(x);
+                    const double dg = s.uray * (x * phi);
+                    u_eff = s.uray * phi;
+                    gained += dg;
+                    s.uray = s.uray + dg;
+                }
+                if (a.quantity == 1) q_dep = u_eff * ds;
+                else if (a.quantity == 2) q_dep = u_eff * (s.vx * a.dt);
+                else if (a.quantity == 3) q_dep = u_eff * (s.vy * a.dt);
+                else if (a.quantity == 4) q_dep = u_eff * (s.vz * a.dt);
+            }
             if (DEPOSIT != 3) {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) wgt[c] = wgt[c] * inc;   // a_c * increment, :341-348
@@ -870,6 +929,7 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
                 } else {
                     inc = s.uray;
                 }
+                if (CBET && a.quantity != 0) inc = q_dep;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) wgt[c] = wgt[c] * inc;
             }
@@ -945,6 +1005,12 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
         a.timeline[3 * (long)blockIdx.x + 2] = (unsigned long long)(w_steps_miss >> 16);
     }
 #endif
+    if (CBET && a.beam_gain) {  // one fp64 atomic per wave
+        double t = gained;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, kWave);
+        if (lane == 0 && t != 0.0) atomicAdd(&a.beam_gain[beam], t);
+    }
     // counters: one atomic per wave and counter
     const int tot_steps = wave_sum(nsteps), tot_rays = wave_sum(launched), tot_at = wave_sum(n_atomics),
               tot_ev = wave_sum(n_evict);
@@ -958,6 +1024,137 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
             atomicAdd(&a.counters[kCntWaveStepsMiss], (unsigned long long)(w_steps_miss & 0xFFFFu));
             atomicAdd(&a.counters[kCntWaveStepsWide], (unsigned long long)(w_slabs_wide & 0xFFFFu));
             atomicAdd(&a.counters[kCntSlabsRetired], (unsigned long long)(w_slabs_wide >> 16));
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// CBET extension (no reference counterpart; model and layout in DESIGN.md section 10).
+// Deposit-grid cell (hi,hj,hk) takes its plasma state from node (hi-1,hj-1,hk-1), clamped.
+// ---------------------------------------------------------------------------------------------
+struct CellState {
+    double frac, eps, rt, ux, uy, uz;   // ne/ncrit, 1 - ne/ncrit, sqrt(eps), flow velocity
+};
+
+__device__ __forceinline__ CellState cell_state(const GainArgs &a, long h)
+{
+    const int sYh = a.nz + 2;
+    const long sXh = (long)(a.ny + 2) * sYh;
+    const int hi = (int)(h / sXh);
+    const int rem = (int)(h - hi * sXh);
+    const int hj = rem / sYh, hk = rem - hj * sYh;
+    const int i = hi < 1 ? 0 : (hi > a.nx ? a.nx - 1 : hi - 1);
+    const int j = hj < 1 ? 0 : (hj > a.ny ? a.ny - 1 : hj - 1);
+    const int k = hk < 1 ? 0 : (hk > a.nz ? a.nz - 1 : hk - 1);
+    CellState c;
+    c.frac = a.ne3d[((long)i * a.ny + j) * a.nz + k] / a.ncrit;
+    c.eps = 1.0 - c.frac;
+    c.rt = c.eps > 0.0 ? sqrt(c.eps) : 0.0;
+    const double xc = i * a.dx + a.xmin, yc = j * a.dy + a.ymin, zc = k * a.dz + a.zmin;
+    const double rr = sqrt(xc * xc + yc * yc + zc * zc);
+    double t = (rr - a.mach_r0) / (a.mach_r1 - a.mach_r0);
+    if (t < 0.0) t = 0.0;
+    if (t > 1.0) t = 1.0;
+    const double um = (a.mach_0 + (a.mach_1 - a.mach_0) * t) * a.cs;
+    c.ux = c.uy = c.uz = 0.0;
+    if (rr > 0.0) { c.ux = um * (xc / rr); c.uy = um * (yc / rr); c.uz = um * (zc / rr); }
+    return c;
+}
+
+// In place: (E, Dx, Dy, Dz) -> (I, kx, ky, kz) per beam and cell; a beam that is absent from a cell
+// (no energy, no direction, or an over-critical cell) gets I = 0.  One thread per (beam, cell).
+__global__ void __launch_bounds__(256) k_field_normalize(const GainArgs a)
+{
+    const long hsize = (long)(a.nx + 2) * (a.ny + 2) * (a.nz + 2);
+    const long total = hsize * a.nbeams;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const long h = idx % hsize;
+        double *f0 = a.fields + idx, *f1 = f0 + total, *f2 = f1 + total, *f3 = f2 + total;
+        const double E = *f0, ax = *f1, ay = *f2, az = *f3;
+        const CellState c = cell_state(a, h);
+        const double dn = sqrt(ax * ax + ay * ay + az * az);
+        double I = 0.0, kx = 0.0, ky = 0.0, kz = 0.0;
+        if (c.eps > 0.0 && E > 0.0 && dn > 0.0) {
+            const double kmag = a.k0 * c.rt;
+            const double ds_node = (kC * c.rt) * a.dt;  // group speed x dt: energy x length -> intensity
+            I = E / ds_node;
+            kx = kmag * (ax / dn);
+            ky = kmag * (ay / dn);
+            kz = kmag * (az / dn);
+        }
+        *f0 = I; *f1 = kx; *f2 = ky; *f3 = kz;
+    }
+}
+
+// K_i(cell) = sum_{j != i} G_ij I_j over the beams present in the cell, then under-relaxation into
+// `gain`.  One thread per cell (consecutive lanes = consecutive z cells: every load below is a
+// coalesced 512-B row of one beam's grid); the beam loops run over the beams present ANYWHERE in the
+// wave's 64 cells (a ballot-built bit mask), so empty beams cost nothing.
+__global__ void __launch_bounds__(256) k_gain_field(const GainArgs a)
+{
+    const long hsize = (long)(a.nx + 2) * (a.ny + 2) * (a.nz + 2);
+    const long total = hsize * a.nbeams;
+    const double iaw2 = a.iaw * a.iaw;
+    const long stride = (long)gridDim.x * blockDim.x;
+    double sum_change = 0.0, sum_abs = 0.0;
+    const long rounds = (hsize + stride - 1) / stride;  // every thread runs the same number of rounds: ballots stay wave-wide
+    for (long rd = 0; rd < rounds; ++rd) {
+        const long h0 = rd * stride + (long)blockIdx.x * blockDim.x + threadIdx.x;
+        const bool valid = h0 < hsize;
+        const long h = valid ? h0 : hsize - 1;
+        const double *fI = a.fields + h, *fx = fI + total, *fy = fx + total, *fz = fy + total;
+        unsigned long long mask = 0ull;  // beams present in some cell of this wave
+        for (int b = 0; b < a.nbeams; ++b)
+            if (__builtin_amdgcn_ballot_w64(valid && fI[(long)b * hsize] > 0.0) != 0ull) mask |= 1ull << b;
+        double pref = 0.0, ux = 0.0, uy = 0.0, uz = 0.0;
+        if (mask != 0ull) {
+            const CellState c = cell_state(a, h);
+            if (c.eps > 0.0) pref = a.gain_const * c.frac * (1.0 / a.iaw) / c.rt;
+            ux = c.ux; uy = c.uy; uz = c.uz;
+        }
+        for (int bi = 0; bi < a.nbeams; ++bi) {
+            double raw = 0.0;
+            if ((mask >> bi) & 1ull) {
+                const double Ii = fI[(long)bi * hsize];
+                const double kxi = fx[(long)bi * hsize], kyi = fy[(long)bi * hsize], kzi = fz[(long)bi * hsize];
+                double acc = 0.0;
+                unsigned long long m = mask & ~(1ull << bi);
+                while (m != 0ull) {
+                    const int bj = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const double Ij = fI[(long)bj * hsize];
+                    const double qx = fx[(long)bj * hsize] - kxi, qy = fy[(long)bj * hsize] - kyi, qz = fz[(long)bj * hsize] - kzi;
+                    const double kiaw = sqrt(qx * qx + qy * qy + qz * qz);
+                    if (Ii > 0.0 && Ij > 0.0 && kiaw > 0.0) {
+                        const double eta = (0.0 - (qx * ux + qy * uy + qz * uz)) / (kiaw * a.cs + 1e-10);
+                        const double e2 = eta * eta;
+                        const double P = iaw2 * eta / ((e2 - 1.0) * (e2 - 1.0) + iaw2 * e2);
+                        acc += pref * P * Ij;
+                    }
+                }
+                raw = acc;
+            }
+            if (valid) {
+                double *gp = a.gain + (long)bi * hsize + h;
+                const double old = *gp;
+                const double nw = old + a.relax * (raw - old);
+                *gp = nw;
+                sum_change += fabs(nw - old);
+                sum_abs += fabs(nw);
+            }
+        }
+    }
+    if (a.change) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            sum_change += __shfl_xor(sum_change, off, kWave);
+            sum_abs += __shfl_xor(sum_abs, off, kWave);
+        }
+        if ((threadIdx.x & (kWave - 1)) == 0) {
+            atomicAdd(&a.change[0], sum_change);
+            atomicAdd(&a.change[1], sum_abs);
         }
     }
 }
@@ -977,6 +1174,15 @@ hipError_t launch_tabulate(const TabulateArgs &a, hipStream_t stream)
 template <int DEPOSIT, int WL, int RL, int PRE, bool FLIP, bool TWOBOX, bool IDX64>
 static void launch_k(const TraceArgs &a, dim3 grid, hipStream_t stream)
 {
+    if constexpr (DEPOSIT == 3 && TWOBOX && RL == 0 && PRE == 0) {  // CBET hooks: default configuration only
+      if (a.gain || a.quantity != 0 || a.beam_gain) {
+        if (a.absorption == 1)
+            hipLaunchKernelGGL((k_trace<DEPOSIT, WL, RL, PRE, FLIP, TWOBOX, IDX64, true, true>), grid, dim3(kWave), 0, stream, a);
+        else
+            hipLaunchKernelGGL((k_trace<DEPOSIT, WL, RL, PRE, FLIP, TWOBOX, IDX64, false, true>), grid, dim3(kWave), 0, stream, a);
+        return;
+      }
+    }
     if (a.absorption == 1)
         hipLaunchKernelGGL((k_trace<DEPOSIT, WL, RL, PRE, FLIP, TWOBOX, IDX64, true>), grid, dim3(kWave), 0, stream, a);
     else
@@ -1015,6 +1221,24 @@ static void dispatch_trace(const TraceArgs &a, int variant, int wl, int rl, int 
         default: launch_k<3, 3, 2, 2, false, false, IDX64>(a, grid, stream); break;
         }
     }
+}
+
+hipError_t launch_field_normalize(const GainArgs &a, hipStream_t stream)
+{
+    const long total = (long)(a.nx + 2) * (a.ny + 2) * (a.nz + 2) * a.nbeams;
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(k_field_normalize, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_gain_field(const GainArgs &a, hipStream_t stream)
+{
+    const long hsize = (long)(a.nx + 2) * (a.ny + 2) * (a.nz + 2);
+    long blocks = (hsize + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(k_gain_field, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
 }
 
 hipError_t audit_violations(unsigned long long *out, bool reset, hipStream_t stream)

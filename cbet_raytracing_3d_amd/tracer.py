@@ -94,6 +94,77 @@ class RayTracer:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         return self.ctx.counters(stream, reset)
 
+    # ---- CBET stage (parity unpinned, see include/cbet_mi355x.h) --------------
+    def tabulate(self):
+        """Fill the context's node tables from the radial profiles (what launch() does first)."""
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        api.tabulate_plasma(self.ctx, self.params, self.d_te, self.d_r, self.d_ne, stream)
+
+    def launch_cbet(self, out, gain_params, quantity=0, gain=None, beam_gain=None, shard_index=0,
+                    shard_count=1, ne3d=None, kappa3d=None):
+        """One trace with the CBET hooks on torch's current stream (node tables must be filled:
+        tabulate(), or pass ne3d / kappa3d).  out: (n+2)^3 grid or nbeams of them."""
+        per_beam = out.dim() == 4
+        want = ((self.params.nbeams,) + self.grid_shape) if per_beam else self.grid_shape
+        if out.dtype != torch.float64 or not out.is_contiguous() or tuple(out.shape) != want:
+            raise ValueError("out must be a contiguous float64 tensor of shape %s (or nbeams x that)" % (self.grid_shape,))
+        if gain is not None and (gain.dtype != torch.float64 or not gain.is_contiguous() or
+                                 tuple(gain.shape) != (self.params.nbeams,) + self.grid_shape):
+            raise ValueError("gain must be a contiguous float64 tensor of shape nbeams x %s" % (self.grid_shape,))
+        p = self.params.copy(per_beam_grids=1 if per_beam else 0, beam_lo=0, beam_hi=self.params.nbeams,
+                             shard_index=shard_index, shard_count=shard_count)
+        d = self.derived
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        api.trace_cbet(0, d.nindices, ne3d, kappa3d, gain, quantity, out, beam_gain, self.d_bbeam_norm,
+                       self.d_beam_norm, self.d_pow_r, self.d_phase_r, d.xconst, d.yconst, d.zconst, p,
+                       gain_params, self.ctx, stream)
+        return out
+
+    def new_fields(self):
+        """Zeroed [4][nbeams][(n+2)^3] field array (energy x length, energy x displacement x/y/z)."""
+        return torch.zeros((4, self.params.nbeams) + self.grid_shape, dtype=torch.float64, device=self.device)
+
+    def gain_field(self, fields, gain, gain_params, change=None, ne3d=None):
+        """Normalise `fields` in place and relax `gain` towards the gain coefficient they imply."""
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        api.gain_field(fields, ne3d, gain, change, self.params, gain_params, self.ctx, stream)
+        return gain
+
+    def cbet_solve(self, edep, gain_params, rank=0, world_size=1, group=None, fields=None, gain=None):
+        """The CBET iteration, one rank's share: field passes (ray bundles sharded like a plain pass,
+        fields all-reduced between passes) until the gain coefficient stops changing, then one
+        deposition pass ADDED into `edep` (not reduced here: use allreduce_grid).  Returns a dict
+        {passes, converged, change, beam_gain (all-reduced), imbalance}.  Single-rank callers can use
+        the native loop instead: api.cbet_solve."""
+        si, sc = shard_of_rank(rank, world_size)
+        fields = self.new_fields() if fields is None else fields
+        gain = self.new_grid(per_beam=True) if gain is None else gain.zero_()
+        change = torch.zeros(2, dtype=torch.float64, device=self.device)
+        beam_gain = torch.zeros(self.params.nbeams, dtype=torch.float64, device=self.device)
+        self.tabulate()
+        rep = {"passes": 0, "converged": False, "change": float("inf")}
+        for it in range(gain_params.max_passes):
+            fields.zero_()
+            for q in (1, 2, 3, 4):
+                self.launch_cbet(fields[q - 1], gain_params, quantity=q, gain=gain if it else None,
+                                 shard_index=si, shard_count=sc)
+            allreduce_grid(fields, group)
+            change.zero_()
+            self.gain_field(fields, gain, gain_params, change)
+            ch = change.cpu()
+            rep["passes"] = it + 1
+            rep["change"] = float(ch[0] / ch[1]) if float(ch[1]) > 0 else 0.0
+            if rep["change"] < gain_params.tolerance:
+                rep["converged"] = True
+                break
+        self.launch_cbet(edep, gain_params, quantity=0, gain=gain, beam_gain=beam_gain, shard_index=si, shard_count=sc)
+        allreduce_grid(beam_gain, group)
+        bg = beam_gain.cpu().numpy()
+        rep["beam_gain"] = bg
+        rep["imbalance"] = float(abs(bg.sum()) / np.abs(bg).sum()) if np.abs(bg).sum() > 0 else 0.0
+        rep["gain"] = gain
+        return rep
+
     def node_tables(self):
         """Copies of the context's node tables (ne3d, kappa3d) as numpy arrays, for tests."""
         n = self.params.nx * self.params.ny * self.params.nz

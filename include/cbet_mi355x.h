@@ -32,6 +32,7 @@ extern "C" {
 #define CBET_ECOMM (-5)    /* RCCL failure in the multi-GPU orchestrator */
 
 #define CBET_NPHASE 2001   /* length of pow_r / phase_r, main.cu:102-103 */
+#define CBET_MAX_CBET_BEAMS 64 /* the CBET stage keeps a beam-presence bit mask per wavefront */
 
 /* Kernel formulations selectable at run time (cbet_params.kernel_variant). */
 #define CBET_KERNEL_DEFAULT 0        /* the library's best parity-exact kernel */
@@ -252,6 +253,85 @@ long long cbet_write_text(const double *edep, int d0, int d1, int d2, const char
  * edepavg[nx][ny][nz] from the haloed HOST array edep[nx+2][ny+2][nz+2], same summation order.
  */
 int cbet_edep_average(const double *edep, double *edepavg, int nx, int ny, int nz);
+
+/* ---- CBET stage ------------------------------------------------------------- */
+/*
+ * PARITY UNPINNED.  The reference has no cross-beam energy transfer code -- only the unused constants
+ * of def.cuh:94-114 (estat, mach, Z, mi, Te, Ti, iaw, kb, constant1, cs, u_flow) -- so this stage has
+ * no reference output to match.  It implements the steady-state ion-acoustic gain of the ray-based
+ * CBET codes those constants come from, on per-beam FIELDS of the deposit grid:
+ *
+ *   dI_i/ds = I_i K_i,   K_i = sum_{j != i} G_ij I_j,   G_ij = -G_ji
+ *   G_ij = constant1 (8 pi 1e7 / c) (ne/ncrit) (1/iaw) P(eta_ij) / sqrt(1 - ne/ncrit)
+ *   eta_ij = -(k_j - k_i).u / (|k_j - k_i| cs + 1e-10),  P = iaw^2 eta / ((eta^2 - 1)^2 + iaw^2 eta^2)
+ *
+ * with a radial outflow u = Mach(r) cs r_hat (def.cuh:114 refers to an undefined `machnum`).  It is
+ * checked against a CPU restatement of the same model (oracle/, tests/test_gpu_cbet.py), by the exact
+ * antisymmetry of the exchange and by energy conservation at the fixed point.
+ */
+typedef struct cbet_gain_params {
+    double z_ion;          /* def.cuh:100   Z = 3.1                                             */
+    double te_ev, ti_ev;   /* def.cuh:104, 106                                                   */
+    double mi_over_me;     /* def.cuh:101-102  10230                                             */
+    double iaw;            /* def.cuh:107   ion-acoustic wave damping nu_ia / omega_s            */
+    double mach_r0, mach_0, mach_r1, mach_1;  /* Mach number ramps linearly from mach_0 at radius mach_r0 to mach_1 at mach_r1 (clamped outside) */
+    double max_exponent;   /* clamp on |K ds| per ray-step, 0 < max_exponent <= 1                */
+    double relax;          /* K <- K + relax (K_raw - K) between passes, 0 < relax <= 1          */
+    double tolerance;      /* cbet_cbet_solve stops when sum |dK| / sum |K| falls below it       */
+    int max_passes;        /* ... or after this many field passes                                */
+    int reserved_;
+} cbet_gain_params;
+
+typedef struct cbet_cbet_report {
+    int passes;                      /* field passes run                                        */
+    int converged;                   /* 1: tolerance reached                                    */
+    double change;                   /* last sum |dK| / sum |K|                                 */
+    double imbalance;                /* |sum_b gained_b| / sum_b |gained_b| of the final pass   */
+    double beam_gain[CBET_MAX_CBET_BEAMS]; /* energy each beam gained in the final pass          */
+    unsigned long long ray_steps;    /* all ray-steps traced, field passes included             */
+    unsigned long long ray_steps_final; /* ray-steps of the final (deposition) pass              */
+} cbet_cbet_report;
+
+int cbet_gain_params_default(cbet_gain_params *g);
+/* def.cuh:111 constant1, def.cuh:113 cs, and gain_const = constant1 * 8 pi 1e7 / c (any may be NULL) */
+int cbet_gain_constants(const cbet_params *p, const cbet_gain_params *g, double *constant1, double *cs,
+                        double *gain_const);
+/*
+ * cbet_trace_nodes with the CBET hooks.  gain: device [nbeams][(nx+2)(ny+2)(nz+2)] gain coefficient
+ * per beam on the deposit grid (1/cm), or NULL; every ray-step gathers it from its eight deposit
+ * nodes with the deposit weights and multiplies the ray's energy by exp(K |v| dt) before absorption.
+ * quantity: what a step deposits into `out` -- 0 the absorbed energy (the reference's edep), 1 the
+ * step-averaged ray energy x path length, 2/3/4 that energy x displacement along x/y/z.  beam_gain:
+ * device [nbeams], ADDED into: energy each beam gained (may be NULL).  Default kernel knobs only.
+ */
+int cbet_trace_cbet(int b, unsigned nindices, const double *ne3d, const double *kappa3d,
+                    const double *gain, int quantity, double *out, double *beam_gain,
+                    const double *bbeam_norm, const double *beam_norm, const double *pow_r,
+                    const double *phase_r, double xconst, double yconst, double zconst,
+                    const cbet_params *p, const cbet_gain_params *g, cbet_context *ctx, void *stream);
+/*
+ * fields: device [4][nbeams][(n+2)^3] = what quantity 1..4 passes deposited with per_beam_grids;
+ * normalised IN PLACE to (intensity, k_x, k_y, k_z).  gain: device [nbeams][(n+2)^3], updated to
+ * gain + relax (K - gain).  change: device double[2], ADDED into: {sum |new - old|, sum |new|}
+ * (may be NULL).  ne3d NULL = the context's node table.  Needs nbeams <= CBET_MAX_CBET_BEAMS.
+ */
+int cbet_gain_field(double *fields, const double *ne3d, double *gain, double *change,
+                    const cbet_params *p, const cbet_gain_params *g, cbet_context *ctx, void *stream);
+/* Bytes of device workspace cbet_cbet_solve needs: 5 nbeams (n+2)^3 doubles + a few scalars. */
+size_t cbet_cbet_workspace_bytes(const cbet_params *p);
+/*
+ * The whole iteration on the current device: tabulate the plasma; repeat { four field passes with the
+ * current gain -> normalise -> new gain } until converged; then one deposition pass with the
+ * converged gain ADDED into edep (device, (n+2)^3).  Profiles and tables are device pointers as for
+ * cbet_launch_ray_XYZ.  workspace: device memory of cbet_cbet_workspace_bytes() or NULL (allocated
+ * and freed inside).  Honours shard_index / shard_count only with shard_count == 1 (the multi-rank
+ * loop lives above the C ABI: tracer.cbet_solve all-reduces the fields between passes).
+ * Synchronises the stream once per pass (it reads the convergence scalars).
+ */
+int cbet_cbet_solve(double *te_data_g, double *r_data_g, double *ne_data_g, double *edep,
+                    double *bbeam_norm, double *beam_norm, double *pow_r, double *phase_r,
+                    const cbet_params *p, const cbet_gain_params *g, void *workspace,
+                    cbet_context *ctx, void *stream, cbet_cbet_report *report);
 
 #ifdef __cplusplus
 }

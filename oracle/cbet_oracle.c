@@ -235,7 +235,39 @@ typedef struct ray_ctx {
     int atomic;
     double *path; /* optional KAT recording, 8 doubles per step */
     int path_cap;
+    /* CBET extension (UNPINNED: no reference counterpart, see cbet_oracle.h) */
+    const double *gain;   /* [nbeams][(n+2)^3] gain coefficient per beam on the deposit grid, 1/cm; NULL = none */
+    int quantity;         /* what a step deposits: 0 absorbed energy (reference), 1 ray energy x path length, 2..4 ray energy x displacement x/y/z */
+    long grid_stride;     /* doubles between per-beam output grids; 0 = one grid */
+    double max_exponent;  /* clamp on |gain * ds| per step */
+    double *beam_gain;    /* [nbeams] energy gained through CBET (sum over steps of uray_after - uray_before) */
 } ray_ctx;
+
+/* phi(x) = (exp(x) - 1) / x = sum_{n=0}^{17} x^n / (n+1)!  for |x| <= 1, in Horner form from fp64
+ * multiplies and adds only (no libm, no FMA), so the HIP kernel evaluates the identical sequence.
+ * exp(x) = 1 + x phi(x); phi is also the average of exp(x s) over the step, s in [0,1]. */
+static double phi_det(double x)
+{
+    double p = 1.0 / 6402373705728000.0; /* 1/18! */
+    p = p * x + 1.0 / 355687428096000.0;
+    p = p * x + 1.0 / 20922789888000.0;
+    p = p * x + 1.0 / 1307674368000.0;
+    p = p * x + 1.0 / 87178291200.0;
+    p = p * x + 1.0 / 6227020800.0;
+    p = p * x + 1.0 / 479001600.0;
+    p = p * x + 1.0 / 39916800.0;
+    p = p * x + 1.0 / 3628800.0;
+    p = p * x + 1.0 / 362880.0;
+    p = p * x + 1.0 / 40320.0;
+    p = p * x + 1.0 / 5040.0;
+    p = p * x + 1.0 / 720.0;
+    p = p * x + 1.0 / 120.0;
+    p = p * x + 1.0 / 24.0;
+    p = p * x + 1.0 / 6.0;
+    p = p * x + 0.5;
+    p = p * x + 1.0;
+    return p;
+}
 
 static void deposit(const ray_ctx *c, long idx, double v)
 {
@@ -292,6 +324,9 @@ static int trace_one(const ray_ctx *c, int beam, int pre_raynum)
     vy = sq(K_C) * ((vy / knorm) * w) / d->omega;
     vz = sq(K_C) * ((vz / knorm) * w) / d->omega;
 
+    const long beam_off = (long)beam * c->grid_stride; /* per-beam output grids (CBET extension) */
+    double gained = 0.0;
+
     int steps = 0;
     for (int tt = 0; tt < d->nt; ++tt) { /* :207 */
         /* :212-238 central-difference neighbours, one-sided at the faces */
@@ -346,6 +381,51 @@ static int trace_one(const ray_ctx *c, int beam, int pre_raynum)
             }
         }
 
+        /* CBET extension (unpinned), part 1: the step's path length; u_eff = the ray's energy averaged
+         * over the step (= the arriving energy when no gain acts) is what the field passes deposit */
+        double ds = 0.0;
+        if (c->gain || c->quantity == 1) ds = sqrt(vx * vx + vy * vy + vz * vz) * dt;
+        double u_eff = uray;
+
+        /* :319-336 offsets from the node and the eight linear weights */
+        double ox = fx - ci - 0.5;
+        double oy = fy - cj - 0.5;
+        double oz = fz - ck - 0.5;
+        double dm = 1.0 - fabs(ox);
+        double dn = 1.0 - fabs(oy);
+        double dl = 1.0 - fabs(oz);
+        double a1 = (1.0 - dl) * (1.0 - dn) * (1.0 - dm);
+        double a2 = (1.0 - dl) * (1.0 - dn) * dm;
+        double a3 = dl * (1.0 - dn) * (1.0 - dm);
+        double a4 = dl * (1.0 - dn) * dm;
+        double a5 = (1.0 - dl) * dn * (1.0 - dm);
+        double a6 = (1.0 - dl) * dn * dm;
+        double a7 = dl * dn * (1.0 - dm);
+        double a8 = dl * dn * dm;
+        int sx = (ox < 0) ? -1 : 1, sy = (oy < 0) ? -1 : 1, sz = (oz < 0) ? -1 : 1; /* :338-339 */
+        const long sYh = (long)nz + 2, sXh = ((long)ny + 2) * ((long)nz + 2);
+        const long hbase = (long)(ci + 1) * sXh + (long)(cj + 1) * sYh + (ck + 1);
+
+        /* CBET extension (unpinned), part 2: the gain coefficient is gathered from the ray's eight deposit
+         * nodes with the deposit weights (so that what the rays gain equals sum_nodes K * field, and the
+         * pairwise antisymmetry of K makes the exchange between beams conservative once fields and K
+         * are consistent); the ray's energy is multiplied by exp(K ds) = 1 + x phi(x) before absorption */
+        if (c->gain) {
+            const double *gk = c->gain + (long)beam * d->edep_size;
+            const double k12 = a1 * gk[hbase] + a2 * gk[hbase + sx * sXh];
+            const double k34 = a3 * gk[hbase + sz] + a4 * gk[hbase + sx * sXh + sz];
+            const double k56 = a5 * gk[hbase + sy * sYh] + a6 * gk[hbase + sx * sXh + sy * sYh];
+            const double k78 = a7 * gk[hbase + sy * sYh + sz] + a8 * gk[hbase + sx * sXh + sy * sYh + sz];
+            double x = ((k12 + k34) + (k56 + k78)) * ds;
+            if (x > c->max_exponent) x = c->max_exponent;
+            if (x < -c->max_exponent) x = -c->max_exponent;
+            const double phi = phi_det(x);
+            const double dg = uray * (x * phi);
+            u_eff = uray * phi;
+            gained += dg;
+            uray = uray + dg;
+        }
+
         /* :296-311 inverse-bremsstrahlung absorption at the new node */
         double inc;
         if (c->kap3d) { /* caller-supplied absorption factor per node (= ed/ncrit*nuei*dt, see node_tables) */
@@ -369,27 +449,16 @@ static int trace_one(const ray_ctx *c, int beam, int pre_raynum)
             }
         }
 
-        /* :319-336 offsets from the node and the eight linear weights */
-        double ox = fx - ci - 0.5;
-        double oy = fy - cj - 0.5;
-        double oz = fz - ck - 0.5;
-        double dm = 1.0 - fabs(ox);
-        double dn = 1.0 - fabs(oy);
-        double dl = 1.0 - fabs(oz);
-        double a1 = (1.0 - dl) * (1.0 - dn) * (1.0 - dm);
-        double a2 = (1.0 - dl) * (1.0 - dn) * dm;
-        double a3 = dl * (1.0 - dn) * (1.0 - dm);
-        double a4 = dl * (1.0 - dn) * dm;
-        double a5 = (1.0 - dl) * dn * (1.0 - dm);
-        double a6 = (1.0 - dl) * dn * dm;
-        double a7 = dl * dn * (1.0 - dm);
-        double a8 = dl * dn * dm;
-        int sx = (ox < 0) ? -1 : 1, sy = (oy < 0) ? -1 : 1, sz = (oz < 0) ? -1 : 1; /* :338-339 */
+
+        if (c->quantity == 1) inc = u_eff * ds;             /* energy x path length */
+        else if (c->quantity == 2) inc = u_eff * (vx * dt); /* ... x displacement components */
+        else if (c->quantity == 3) inc = u_eff * (vy * dt);
+        else if (c->quantity == 4) inc = u_eff * (vz * dt);
 
         /* :341-348 with :5-7's index */
         {
-            const long sY = (long)nz + 2, sX = ((long)ny + 2) * ((long)nz + 2);
-            long base = (long)(ci + 1) * sX + (long)(cj + 1) * sY + (ck + 1);
+            const long sY = sYh, sX = sXh;
+            long base = beam_off + hbase;
             deposit(c, base, a1 * inc);
             deposit(c, base + sx * sX, a2 * inc);
             deposit(c, base + sz, a3 * inc);
@@ -412,6 +481,12 @@ static int trace_one(const ray_ctx *c, int beam, int pre_raynum)
             py < (ymin - (dy / 2.0)) || py > (ymax + (dy / 2.0)) || pz < (zmin - (dz / 2.0)) ||
             pz > (zmax + (dz / 2.0)))
             break;
+    }
+    if (c->beam_gain) {
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+        c->beam_gain[beam] += gained;
     }
     return steps;
 }
@@ -573,4 +648,171 @@ void cbet_oracle_node_tables(const cbet_oracle_config *cfg, const double *r_prof
                 ne3d[idx] = ed;
                 if (kap3d) kap3d[idx] = ed / d.ncrit * nuei * d.dt;
             }
+}
+
+/* =================================================================================================
+ * CBET extension -- PARITY UNPINNED.  The reference has no cross-beam energy transfer code, only the
+ * unused constants of def.cuh:94-114; nothing below can be checked against it.  The model is the
+ * steady-state ion-acoustic gain of the 2-D ray-based CBET codes those constants come from, written
+ * for per-beam intensity / direction FIELDS on the grid:
+ *
+ *   dI_i/ds = I_i * K_i,     K_i(node) = sum_{j != i} G_ij I_j,    G_ij = -G_ji
+ *   G_ij = gain_const * (ne/ncrit) * (1/iaw) * P(eta_ij) / sqrt(eps),   eps = 1 - ne/ncrit
+ *   eta_ij = -(k_j - k_i).u / (|k_j - k_i| cs + 1e-10),  P(eta) = iaw^2 eta / ((eta^2-1)^2 + iaw^2 eta^2)
+ *   k_b = (omega/c) sqrt(eps) * D_b/|D_b|,  u = Mach(r) cs r_hat  (all beams share one frequency)
+ *
+ * This file is the checker of the HIP implementation of that model and nothing more.
+ * ================================================================================================= */
+void cbet_oracle_gain_default(cbet_oracle_gain_config *g)
+{
+    g->z_ion = 3.1;          /* def.cuh:100 */
+    g->te_ev = 2.0e3;        /* def.cuh:104 */
+    g->ti_ev = 1.0e3;        /* def.cuh:106 */
+    g->mi_over_me = 10230.0; /* def.cuh:101-102 */
+    g->iaw = 0.2;            /* def.cuh:107 */
+    g->mach_r0 = 0.04;       /* def.cuh:114 uses an undefined `machnum`: a radial outflow ramp stands in */
+    g->mach_0 = 0.4;
+    g->mach_r1 = 0.13;
+    g->mach_1 = 2.4;
+    g->max_exponent = 1.0;
+}
+
+void cbet_oracle_gain_constants(const cbet_oracle_config *cfg, const cbet_oracle_gain_config *g,
+                                double *constant1, double *cs, double *gain_const)
+{
+    cbet_oracle_derived d;
+    cbet_oracle_derive(cfg, &d);
+    const double estat = 4.80320427e-10;             /* def.cuh:98 */
+    const double kb = 1.3806485279e-16;              /* def.cuh:108 */
+    const double te_k = g->te_ev * 11604.5052;       /* def.cuh:103 */
+    const double ti_k = g->ti_ev * 11604.5052;       /* def.cuh:105 */
+    const double mi_kg = g->mi_over_me * K_ME;       /* def.cuh:102 */
+    /* def.cuh:111 */
+    const double c1 = (pow(estat, 2)) / (4 * (1.0e3 * K_ME) * K_C * d.omega * kb * te_k * (1 + 3 * ti_k / (g->z_ion * te_k)));
+    /* def.cuh:113 */
+    const double sound = 1e2 * sqrt(K_EC * (g->z_ion * g->te_ev + 3.0 * g->ti_ev) / mi_kg);
+    if (constant1) *constant1 = c1;
+    if (cs) *cs = sound;
+    if (gain_const) *gain_const = c1 * (8.0 * M_PI * 1.0e7 / K_C); /* |E|^2 = 8 pi 1e7 I / c, I in W/cm^2 */
+}
+
+long long cbet_oracle_trace_cbet(const cbet_oracle_config *cfg, const cbet_oracle_gain_config *g,
+                                 const double *beam_norm, const double *ne3d, const double *kap3d,
+                                 const double *gain, int quantity, int per_beam, double *out,
+                                 double *beam_gain, int nthreads)
+{
+    static double phase_r[CBET_ORACLE_NPHASE], pow_r[CBET_ORACLE_NPHASE];
+    ray_ctx c;
+    ctx_init(&c, cfg, beam_norm, NULL, NULL, NULL, phase_r, pow_r, out, 1);
+    c.ne3d = ne3d;
+    c.kap3d = kap3d;
+    c.gain = gain;
+    c.quantity = quantity;
+    c.grid_stride = per_beam ? c.d.edep_size : 0;
+    c.max_exponent = g->max_exponent;
+    c.beam_gain = beam_gain;
+    if (beam_gain) memset(beam_gain, 0, sizeof(double) * cfg->nbeams);
+    const int nrays = c.d.nrays;
+    long long total = 0;
+    for (int beam = 0; beam < cfg->nbeams; ++beam) {
+        long long beam_steps = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads > 1 ? nthreads : 1) reduction(+ : beam_steps)
+#endif
+        for (int id = 0; id < nrays; ++id)
+            if (id_traced_d(cfg, &c.d, id)) beam_steps += trace_one(&c, beam, id);
+        total += beam_steps;
+    }
+    return total;
+}
+
+#define CBET_ORACLE_MAX_BEAMS 64
+
+void cbet_oracle_gain_field(const cbet_oracle_config *cfg, const cbet_oracle_gain_config *g,
+                            const double *fields, const double *ne3d, double relax, double *gain,
+                            double *change, int nthreads)
+{
+    cbet_oracle_derived d;
+    cbet_oracle_derive(cfg, &d);
+    double cs, gain_const;
+    cbet_oracle_gain_constants(cfg, g, NULL, &cs, &gain_const);
+    const int nx = cfg->nx, ny = cfg->ny, nz = cfg->nz, nb = cfg->nbeams;
+    const long sY = (long)nz + 2, sX = ((long)ny + 2) * ((long)nz + 2);
+    const long hsize = d.edep_size;
+    const double iaw2 = g->iaw * g->iaw;
+    const double k0 = d.omega / K_C;
+    double sum_change = 0.0, sum_abs = 0.0;
+    if (nb > CBET_ORACLE_MAX_BEAMS) { fprintf(stderr, "cbet_oracle_gain_field: more than 64 beams\n"); abort(); }
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nthreads > 1 ? nthreads : 1) reduction(+ : sum_change, sum_abs)
+#endif
+    for (int hi = 0; hi < nx + 2; ++hi)
+        for (int hj = 0; hj < ny + 2; ++hj)
+            for (int hk = 0; hk < nz + 2; ++hk) {
+                /* deposit-grid cell (hi,hj,hk) takes its plasma state from node (hi-1,hj-1,hk-1), clamped */
+                const int i = hi < 1 ? 0 : (hi > nx ? nx - 1 : hi - 1);
+                const int j = hj < 1 ? 0 : (hj > ny ? ny - 1 : hj - 1);
+                const int k = hk < 1 ? 0 : (hk > nz ? nz - 1 : hk - 1);
+                const long node = ((long)i * ny + j) * nz + k;
+                const long h = (long)hi * sX + (long)hj * sY + hk;
+                double raw[CBET_ORACLE_MAX_BEAMS], kx[CBET_ORACLE_MAX_BEAMS], ky[CBET_ORACLE_MAX_BEAMS],
+                    kz[CBET_ORACLE_MAX_BEAMS], in[CBET_ORACLE_MAX_BEAMS];
+                int present[CBET_ORACLE_MAX_BEAMS], np = 0;
+                for (int b = 0; b < nb; ++b) raw[b] = 0.0;
+                const double frac = ne3d[node] / d.ncrit;
+                const double eps = 1.0 - frac;
+                if (eps > 0.0) {
+                    const double rt = sqrt(eps);
+                    const double kmag = k0 * rt;
+                    const double ds_node = (K_C * rt) * d.dt; /* group speed x dt: turns energy x length into intensity */
+                    const double xc = i * d.dx + cfg->xmin, yc = j * d.dy + cfg->ymin, zc = k * d.dz + cfg->zmin;
+                    const double rr = sqrt(xc * xc + yc * yc + zc * zc);
+                    double t = (rr - g->mach_r0) / (g->mach_r1 - g->mach_r0);
+                    if (t < 0.0) t = 0.0;
+                    if (t > 1.0) t = 1.0;
+                    const double um = (g->mach_0 + (g->mach_1 - g->mach_0) * t) * cs;
+                    double ux = 0.0, uy = 0.0, uz = 0.0;
+                    if (rr > 0.0) { ux = um * (xc / rr); uy = um * (yc / rr); uz = um * (zc / rr); }
+                    const double pref = gain_const * frac * (1.0 / g->iaw) / rt;
+                    for (int b = 0; b < nb; ++b) {
+                        const double E = fields[(0L * nb + b) * hsize + h];
+                        const double ax = fields[(1L * nb + b) * hsize + h];
+                        const double ay = fields[(2L * nb + b) * hsize + h];
+                        const double az = fields[(3L * nb + b) * hsize + h];
+                        const double dn = sqrt(ax * ax + ay * ay + az * az);
+                        if (E > 0.0 && dn > 0.0) {
+                            in[b] = E / ds_node;
+                            kx[b] = kmag * (ax / dn);
+                            ky[b] = kmag * (ay / dn);
+                            kz[b] = kmag * (az / dn);
+                            present[np++] = b;
+                        }
+                    }
+                    for (int pi = 0; pi < np; ++pi) {
+                        const int bi = present[pi];
+                        double acc = 0.0;
+                        for (int pj = 0; pj < np; ++pj) {
+                            const int bj = present[pj];
+                            if (bj == bi) continue;
+                            const double qx = kx[bj] - kx[bi], qy = ky[bj] - ky[bi], qz = kz[bj] - kz[bi];
+                            const double kiaw = sqrt(qx * qx + qy * qy + qz * qz);
+                            if (kiaw > 0.0) {
+                                const double eta = (0.0 - (qx * ux + qy * uy + qz * uz)) / (kiaw * cs + 1e-10);
+                                const double e2 = eta * eta;
+                                const double P = iaw2 * eta / ((e2 - 1.0) * (e2 - 1.0) + iaw2 * e2);
+                                acc += pref * P * in[bj];
+                            }
+                        }
+                        raw[bi] = acc;
+                    }
+                }
+                for (int b = 0; b < nb; ++b) {
+                    const double old = gain[(long)b * hsize + h];
+                    const double nw = old + relax * (raw[b] - old);
+                    gain[(long)b * hsize + h] = nw;
+                    sum_change += fabs(nw - old);
+                    sum_abs += fabs(nw);
+                }
+            }
+    if (change) { change[0] = sum_change; change[1] = sum_abs; }
 }

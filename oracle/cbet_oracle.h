@@ -123,6 +123,38 @@ void cbet_oracle_node_tables(const cbet_oracle_config *cfg, const double *r_prof
                              const double *ne_prof, const double *te_prof, double *ne3d,
                              double *kap3d);
 
+/* ---- CBET extension: PARITY UNPINNED -----------------------------------------------------------
+ * The reference contains no cross-beam energy transfer code (only the unused constants of
+ * def.cuh:94-114), so nothing here can be checked against it.  These functions restate on the CPU the
+ * field-based gain model the product implements and serve only as the checker
+ * of that HIP implementation. */
+typedef struct cbet_oracle_gain_config {
+    double z_ion;              /* def.cuh:100 */
+    double te_ev, ti_ev;       /* def.cuh:104,106 */
+    double mi_over_me;         /* def.cuh:101-102 */
+    double iaw;                /* def.cuh:107 */
+    double mach_r0, mach_0, mach_r1, mach_1; /* radial outflow: Mach number ramps linearly from mach_0 at r0 to mach_1 at r1 */
+    double max_exponent;       /* clamp on |gain * path length| per ray-step */
+} cbet_oracle_gain_config;
+
+void cbet_oracle_gain_default(cbet_oracle_gain_config *g);
+/* def.cuh:111 constant1, def.cuh:113 cs, and constant1 * 8 pi 1e7 / c */
+void cbet_oracle_gain_constants(const cbet_oracle_config *cfg, const cbet_oracle_gain_config *g,
+                                double *constant1, double *cs, double *gain_const);
+/* Node-table ray loop of cbet_oracle_trace_tables with the CBET hooks: every step multiplies the ray
+ * energy by exp(K |v| dt), K = gain[beam][(n+2)^3] gathered from the step's eight deposit nodes with the
+ * deposit weights (gain may be NULL), and deposits `quantity` (0 absorbed energy, 1 arriving ray energy x
+ * path length, 2..4 arriving ray energy x displacement x/y/z) into out (one (n+2)^3 grid, or nbeams of
+ * them when per_beam).  beam_gain[nbeams] (may be NULL) receives the energy each beam gained. */
+long long cbet_oracle_trace_cbet(const cbet_oracle_config *cfg, const cbet_oracle_gain_config *g,
+                                 const double *beam_norm, const double *ne3d, const double *kap3d,
+                                 const double *gain, int quantity, int per_beam, double *out,
+                                 double *beam_gain, int nthreads);
+/* fields[4][nbeams][(n+2)^3] -> gain[nbeams][(n+2)^3] <- gain + relax * (raw - gain); change = {sum |new-old|, sum |new|} */
+void cbet_oracle_gain_field(const cbet_oracle_config *cfg, const cbet_oracle_gain_config *g,
+                            const double *fields, const double *ne3d, double relax, double *gain,
+                            double *change, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

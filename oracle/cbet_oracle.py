@@ -40,6 +40,16 @@ class Derived(C.Structure):
     ]
 
 
+class GainConfig(C.Structure):
+    """CBET extension (parity unpinned) -- see cbet_oracle.h."""
+    _fields_ = [
+        ("z_ion", C.c_double), ("te_ev", C.c_double), ("ti_ev", C.c_double), ("mi_over_me", C.c_double),
+        ("iaw", C.c_double),
+        ("mach_r0", C.c_double), ("mach_0", C.c_double), ("mach_r1", C.c_double), ("mach_1", C.c_double),
+        ("max_exponent", C.c_double),
+    ]
+
+
 def build(force=False):
     """Compile oracle/libcbet_oracle.so with gcc (no GPU, no reference sources involved)."""
     src = os.path.join(_HERE, "cbet_oracle.c")
@@ -87,6 +97,13 @@ def lib():
     L.cbet_oracle_write_text.argtypes = [_dp, C.c_int, C.c_int, C.c_int, C.c_char_p]
     L.cbet_oracle_write_text.restype = C.c_longlong
     L.cbet_oracle_node_tables.argtypes = [C.POINTER(Config), _dp, _dp, _dp, _dp, C.c_void_p]
+    L.cbet_oracle_gain_default.argtypes = [C.POINTER(GainConfig)]
+    L.cbet_oracle_gain_constants.argtypes = [C.POINTER(Config), C.POINTER(GainConfig)] + [C.POINTER(C.c_double)] * 3
+    L.cbet_oracle_trace_cbet.argtypes = [C.POINTER(Config), C.POINTER(GainConfig), _dp, _dp, _dp, C.c_void_p,
+                                         C.c_int, C.c_int, _dp, C.c_void_p, C.c_int]
+    L.cbet_oracle_trace_cbet.restype = C.c_longlong
+    L.cbet_oracle_gain_field.argtypes = [C.POINTER(Config), C.POINTER(GainConfig), _dp, _dp, C.c_double, _dp,
+                                         _dp, C.c_int]
     _lib = L
     return L
 
@@ -200,3 +217,48 @@ def node_tables(cfg, r, ne, te):
     lib().cbet_oracle_node_tables(C.byref(cfg), np.ascontiguousarray(r), np.ascontiguousarray(ne),
                                   np.ascontiguousarray(te), ne3d, kap.ctypes.data_as(C.c_void_p))
     return ne3d, kap
+
+
+# ---- CBET extension (parity unpinned; checker of the HIP implementation of DESIGN.md section 10) ----
+def gain_default(**overrides):
+    g = GainConfig()
+    lib().cbet_oracle_gain_default(C.byref(g))
+    for k, v in overrides.items():
+        setattr(g, k, v)
+    return g
+
+
+def gain_constants(cfg, g):
+    """(constant1, cs, gain_const) of def.cuh:111,113."""
+    out = [C.c_double() for _ in range(3)]
+    lib().cbet_oracle_gain_constants(C.byref(cfg), C.byref(g), *[C.byref(o) for o in out])
+    return tuple(o.value for o in out)
+
+
+def trace_cbet(cfg, g, beam_norm, ne3d, kap3d, gain=None, quantity=0, per_beam=False, nthreads=1):
+    """Returns (out, ray_steps, beam_gain[nbeams])."""
+    shape = ((cfg.nbeams,) if per_beam else ()) + grid_shape(cfg)
+    out = np.zeros(shape)
+    beam_gain = np.zeros(cfg.nbeams)
+    gp = None
+    if gain is not None:
+        gain = np.ascontiguousarray(gain, dtype=np.float64)
+        assert gain.size == cfg.nbeams * (cfg.nx + 2) * (cfg.ny + 2) * (cfg.nz + 2)
+        gp = gain.ctypes.data_as(C.c_void_p)
+    steps = lib().cbet_oracle_trace_cbet(C.byref(cfg), C.byref(g), np.ascontiguousarray(beam_norm, dtype=np.float64),
+                                         np.ascontiguousarray(ne3d, dtype=np.float64),
+                                         np.ascontiguousarray(kap3d, dtype=np.float64), gp, quantity,
+                                         1 if per_beam else 0, out, beam_gain.ctypes.data_as(C.c_void_p), nthreads)
+    return out, int(steps), beam_gain
+
+
+def gain_field(cfg, g, fields, ne3d, relax=1.0, gain=None, nthreads=1):
+    """fields[4][nbeams][(n+2)^3] -> (gain[nbeams][(n+2)^3], (sum |new-old|, sum |new|))."""
+    if gain is None:
+        gain = np.zeros((cfg.nbeams,) + grid_shape(cfg))
+    fields = np.ascontiguousarray(fields, dtype=np.float64)
+    assert fields.size == 4 * cfg.nbeams * (cfg.nx + 2) * (cfg.ny + 2) * (cfg.nz + 2)
+    change = np.zeros(2)
+    lib().cbet_oracle_gain_field(C.byref(cfg), C.byref(g), fields, np.ascontiguousarray(ne3d, dtype=np.float64),
+                                 float(relax), gain, change, nthreads)
+    return gain, (float(change[0]), float(change[1]))
