@@ -43,6 +43,37 @@ def cpu_baseline(n, r, ne, te, bn):
             "all_cores_note": "threads capped at 16, the CPU share of a 1-GPU job on this pool"}
 
 
+def cbet_leg(api, tr, edep, n):
+    """The CBET iteration on the same workload, reported BESIDE the headline and never
+    part of `value`: the reference has no CBET code, so this stage is parity-unpinned (checked against
+    the CPU restatement of its model and by energy conservation, tests/test_gpu_cbet.py)."""
+    import numpy as np
+    import torch
+    gp = api.default_gain_params()
+    try:
+        ws = torch.empty(api.cbet_workspace_bytes(tr.params) // 8, dtype=torch.float64, device=edep.device)
+    except RuntimeError as exc:   # not enough free HBM next to whatever else the process holds
+        return {"skipped": "workspace allocation failed: %s" % str(exc).splitlines()[0]}
+    stream = torch.cuda.current_stream().cuda_stream
+    args = (tr.d_te, tr.d_r, tr.d_ne, edep, tr.d_bbeam_norm, tr.d_beam_norm, tr.d_pow_r, tr.d_phase_r, tr.params, gp)
+    edep.zero_()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rep = api.cbet_solve(*args, workspace=ws, ctx=tr.ctx, stream=stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    bg = np.array(rep.beam_gain[:tr.params.nbeams])
+    absorbed = float(edep.sum().item())
+    return {"parity": "unpinned (no reference CBET code; model of DESIGN.md section 10)",
+            "workload": "omega60_%dcube_s83177_absorption + CBET fixed-point iteration" % n,
+            "passes": rep.passes, "converged": bool(rep.converged), "gain_change": rep.change,
+            "energy_imbalance": rep.imbalance, "seconds": dt,
+            "ray_steps_traced": int(rep.ray_steps), "ray_steps_per_s": rep.ray_steps / dt,
+            "launches_per_pass": 4, "ray_steps_final_pass": int(rep.ray_steps_final),
+            "absorbed_sum": absorbed, "max_beam_gain_over_mean_absorbed": float(np.abs(bg).max() / (absorbed / len(bg))),
+            "relax": gp.relax, "tolerance": gp.tolerance}
+
+
 def measured_traffic(workload, variant):
     """HBM bytes per k_trace launch from the committed PMC passes (profiles/*/traffic.json:
     (FETCH_SIZE + WRITE_SIZE) * 1 KiB, collected in separate --pmc passes).  None when no profile
@@ -74,6 +105,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank flow on a 1-GPU box together with CBET_BENCH_DEVICE)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cbet", action="store_true", help="skip the (unpinned) CBET-iteration leg reported beside the headline")
     args = ap.parse_args()
 
     import torch
@@ -193,6 +225,8 @@ def main():
                          "window_too_narrow_wave_step_frac": tot[7].item() / max(1.0, tot[5].item()),
                          "slabs_retired_per_wave_step": tot[8].item() / max(1.0, tot[5].item())},
         }
+        if world == 1 and not args.no_cbet:
+            out["cbet"] = cbet_leg(api, tr, edep, n)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, r, ne, te, bn)
         print(json.dumps(out), flush=True)

@@ -679,9 +679,9 @@ int cbet_gain_params_default(cbet_gain_params *g)
     g->mach_r0 = 0.04; g->mach_0 = 0.4;   // def.cuh:114 names an undefined `machnum`; a radial ramp stands in
     g->mach_r1 = 0.13; g->mach_1 = 2.4;
     g->max_exponent = 1.0;
-    g->relax = 1.0;
+    g->relax = 0.5;           // plain fixed-point iteration (1.0) oscillates with 60 overlapping beams (scripts/cbet_converge.py)
     g->tolerance = 1e-4;
-    g->max_passes = 12;
+    g->max_passes = 40;
     return CBET_OK;
 }
 

@@ -131,38 +131,12 @@ class RayTracer:
         return gain
 
     def cbet_solve(self, edep, gain_params, rank=0, world_size=1, group=None, fields=None, gain=None):
-        """The CBET iteration, one rank's share: field passes (ray bundles sharded like a plain pass,
-        fields all-reduced between passes) until the gain coefficient stops changing, then one
-        deposition pass ADDED into `edep` (not reduced here: use allreduce_grid).  Returns a dict
-        {passes, converged, change, beam_gain (all-reduced), imbalance}.  Single-rank callers can use
-        the native loop instead: api.cbet_solve."""
-        si, sc = shard_of_rank(rank, world_size)
-        fields = self.new_fields() if fields is None else fields
-        gain = self.new_grid(per_beam=True) if gain is None else gain.zero_()
-        change = torch.zeros(2, dtype=torch.float64, device=self.device)
-        beam_gain = torch.zeros(self.params.nbeams, dtype=torch.float64, device=self.device)
-        self.tabulate()
-        rep = {"passes": 0, "converged": False, "change": float("inf")}
-        for it in range(gain_params.max_passes):
-            fields.zero_()
-            for q in (1, 2, 3, 4):
-                self.launch_cbet(fields[q - 1], gain_params, quantity=q, gain=gain if it else None,
-                                 shard_index=si, shard_count=sc)
-            allreduce_grid(fields, group)
-            change.zero_()
-            self.gain_field(fields, gain, gain_params, change)
-            ch = change.cpu()
-            rep["passes"] = it + 1
-            rep["change"] = float(ch[0] / ch[1]) if float(ch[1]) > 0 else 0.0
-            if rep["change"] < gain_params.tolerance:
-                rep["converged"] = True
-                break
-        self.launch_cbet(edep, gain_params, quantity=0, gain=gain, beam_gain=beam_gain, shard_index=si, shard_count=sc)
-        allreduce_grid(beam_gain, group)
-        bg = beam_gain.cpu().numpy()
-        rep["beam_gain"] = bg
-        rep["imbalance"] = float(abs(bg.sum()) / np.abs(bg).sum()) if np.abs(bg).sum() > 0 else 0.0
-        rep["gain"] = gain
+        """The CBET iteration, one rank's share (cbet_fixed_point with this device as the engine): the
+        deposition pass is ADDED into `edep` (not reduced here: use allreduce_grid).  Single-rank callers
+        can use the native loop instead: api.cbet_solve."""
+        engine = _DeviceCbetEngine(self, edep, gain_params, fields, gain)
+        rep = cbet_fixed_point(engine, gain_params, rank, world_size, group)
+        rep["gain"] = engine.gain
         return rep
 
     def node_tables(self):
@@ -195,6 +169,71 @@ def allreduce_grid(edep, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(edep, op=dist.ReduceOp.SUM, group=group)
     return edep
+
+
+class _DeviceCbetEngine:
+    """The per-rank compute of the CBET iteration on a RayTracer's device (see cbet_fixed_point)."""
+
+    def __init__(self, tracer, edep, gain_params, fields=None, gain=None):
+        self.tr, self.edep, self.gp = tracer, edep, gain_params
+        self.fields = tracer.new_fields() if fields is None else fields
+        self.gain = tracer.new_grid(per_beam=True) if gain is None else gain
+        self.change = torch.zeros(2, dtype=torch.float64, device=tracer.device)
+        self.beam_gain = torch.zeros(tracer.params.nbeams, dtype=torch.float64, device=tracer.device)
+
+    def begin(self):
+        self.tr.tabulate()
+        self.gain.zero_()
+
+    def field_passes(self, use_gain, shard_index, shard_count):
+        self.fields.zero_()
+        for q in (1, 2, 3, 4):
+            self.tr.launch_cbet(self.fields[q - 1], self.gp, quantity=q, gain=self.gain if use_gain else None,
+                                shard_index=shard_index, shard_count=shard_count)
+        return self.fields
+
+    def update_gain(self, fields):
+        self.change.zero_()
+        self.tr.gain_field(fields, self.gain, self.gp, self.change)
+        return self.change
+
+    def deposit(self, shard_index, shard_count):
+        self.beam_gain.zero_()
+        self.tr.launch_cbet(self.edep, self.gp, quantity=0, gain=self.gain, beam_gain=self.beam_gain,
+                            shard_index=shard_index, shard_count=shard_count)
+        return self.beam_gain
+
+
+def cbet_fixed_point(engine, gain_params, rank=0, world_size=1, group=None):
+    """The CBET fixed-point iteration over `world_size` ranks (parity unpinned).
+
+    Every pass: each rank deposits the four field quantities of ITS share of the ray bundles (the plain
+    pass's interleaved sharding), the fields are summed over ranks with one all-reduce, and every rank
+    updates the full gain coefficient from them (redundantly -- it needs all of it for its own rays).
+    Stops when sum |dK| / sum |K| < tolerance, then runs the deposition pass and all-reduces the
+    per-beam energy balance.  `engine` supplies the per-rank compute:
+        begin(); field_passes(use_gain, shard_index, shard_count) -> fields tensor;
+        update_gain(fields) -> tensor {sum |dK|, sum |K|}; deposit(shard_index, shard_count) -> beam_gain tensor
+    (the device engine is RayTracer.cbet_solve's; the CPU tests drive this loop with an oracle engine).
+    Returns {passes, converged, change, beam_gain, imbalance}."""
+    si, sc = shard_of_rank(rank, world_size)
+    engine.begin()
+    rep = {"passes": 0, "converged": False, "change": float("inf")}
+    for it in range(gain_params.max_passes):
+        fields = engine.field_passes(it > 0, si, sc)
+        allreduce_grid(fields, group)
+        ch = engine.update_gain(fields).cpu()
+        rep["passes"] = it + 1
+        rep["change"] = float(ch[0] / ch[1]) if float(ch[1]) > 0 else 0.0
+        if rep["change"] < gain_params.tolerance:
+            rep["converged"] = True
+            break
+    beam_gain = engine.deposit(si, sc)
+    allreduce_grid(beam_gain, group)
+    bg = beam_gain.cpu().numpy().copy()
+    rep["beam_gain"] = bg
+    rep["imbalance"] = float(abs(bg.sum()) / np.abs(bg).sum()) if np.abs(bg).sum() > 0 else 0.0
+    return rep
 
 
 def traced_pass(tracer, edep, rank=0, world_size=1, group=None, **launch_kw):

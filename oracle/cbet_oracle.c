@@ -726,6 +726,34 @@ long long cbet_oracle_trace_cbet(const cbet_oracle_config *cfg, const cbet_oracl
     return total;
 }
 
+/* The same for an explicit list of (beam, ray id) pairs: one rank's share in the sharding tests. */
+long long cbet_oracle_trace_cbet_list(const cbet_oracle_config *cfg, const cbet_oracle_gain_config *g,
+                                      const double *beam_norm, const double *ne3d, const double *kap3d,
+                                      const double *gain, int quantity, int per_beam, long nitems,
+                                      const int *beams, const int *raynums, double *out,
+                                      double *beam_gain, int nthreads)
+{
+    static double phase_r[CBET_ORACLE_NPHASE], pow_r[CBET_ORACLE_NPHASE];
+    ray_ctx c;
+    ctx_init(&c, cfg, beam_norm, NULL, NULL, NULL, phase_r, pow_r, out, 1);
+    c.ne3d = ne3d;
+    c.kap3d = kap3d;
+    c.gain = gain;
+    c.quantity = quantity;
+    c.grid_stride = per_beam ? c.d.edep_size : 0;
+    c.max_exponent = g->max_exponent;
+    c.beam_gain = beam_gain;
+    if (beam_gain) memset(beam_gain, 0, sizeof(double) * cfg->nbeams);
+    long long total = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads > 1 ? nthreads : 1) reduction(+ : total)
+#endif
+    for (long it = 0; it < nitems; ++it) total += trace_one(&c, beams[it], raynums[it]);
+    return total;
+}
+
+double cbet_oracle_phi(double x) { return phi_det(x); }
+
 #define CBET_ORACLE_MAX_BEAMS 64
 
 void cbet_oracle_gain_field(const cbet_oracle_config *cfg, const cbet_oracle_gain_config *g,

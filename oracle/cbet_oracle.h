@@ -150,6 +150,14 @@ long long cbet_oracle_trace_cbet(const cbet_oracle_config *cfg, const cbet_oracl
                                  const double *beam_norm, const double *ne3d, const double *kap3d,
                                  const double *gain, int quantity, int per_beam, double *out,
                                  double *beam_gain, int nthreads);
+/* The same for an explicit list of (beam, ray id) pairs (one rank's share in the sharding tests). */
+long long cbet_oracle_trace_cbet_list(const cbet_oracle_config *cfg, const cbet_oracle_gain_config *g,
+                                      const double *beam_norm, const double *ne3d, const double *kap3d,
+                                      const double *gain, int quantity, int per_beam, long nitems,
+                                      const int *beams, const int *raynums, double *out,
+                                      double *beam_gain, int nthreads);
+/* (exp(x) - 1) / x as the ray loop evaluates it (|x| <= 1) */
+double cbet_oracle_phi(double x);
 /* fields[4][nbeams][(n+2)^3] -> gain[nbeams][(n+2)^3] <- gain + relax * (raw - gain); change = {sum |new-old|, sum |new|} */
 void cbet_oracle_gain_field(const cbet_oracle_config *cfg, const cbet_oracle_gain_config *g,
                             const double *fields, const double *ne3d, double relax, double *gain,

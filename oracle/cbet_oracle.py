@@ -102,6 +102,11 @@ def lib():
     L.cbet_oracle_trace_cbet.argtypes = [C.POINTER(Config), C.POINTER(GainConfig), _dp, _dp, _dp, C.c_void_p,
                                          C.c_int, C.c_int, _dp, C.c_void_p, C.c_int]
     L.cbet_oracle_trace_cbet.restype = C.c_longlong
+    L.cbet_oracle_trace_cbet_list.argtypes = [C.POINTER(Config), C.POINTER(GainConfig), _dp, _dp, _dp, C.c_void_p,
+                                              C.c_int, C.c_int, C.c_long, _ip, _ip, _dp, C.c_void_p, C.c_int]
+    L.cbet_oracle_trace_cbet_list.restype = C.c_longlong
+    L.cbet_oracle_phi.argtypes = [C.c_double]
+    L.cbet_oracle_phi.restype = C.c_double
     L.cbet_oracle_gain_field.argtypes = [C.POINTER(Config), C.POINTER(GainConfig), _dp, _dp, C.c_double, _dp,
                                          _dp, C.c_int]
     _lib = L
@@ -235,8 +240,12 @@ def gain_constants(cfg, g):
     return tuple(o.value for o in out)
 
 
-def trace_cbet(cfg, g, beam_norm, ne3d, kap3d, gain=None, quantity=0, per_beam=False, nthreads=1):
-    """Returns (out, ray_steps, beam_gain[nbeams])."""
+def phi(x):
+    return lib().cbet_oracle_phi(float(x))
+
+
+def trace_cbet(cfg, g, beam_norm, ne3d, kap3d, gain=None, quantity=0, per_beam=False, nthreads=1, items=None):
+    """Returns (out, ray_steps, beam_gain[nbeams]).  items = (beams, raynums): trace that list only."""
     shape = ((cfg.nbeams,) if per_beam else ()) + grid_shape(cfg)
     out = np.zeros(shape)
     beam_gain = np.zeros(cfg.nbeams)
@@ -245,6 +254,14 @@ def trace_cbet(cfg, g, beam_norm, ne3d, kap3d, gain=None, quantity=0, per_beam=F
         gain = np.ascontiguousarray(gain, dtype=np.float64)
         assert gain.size == cfg.nbeams * (cfg.nx + 2) * (cfg.ny + 2) * (cfg.nz + 2)
         gp = gain.ctypes.data_as(C.c_void_p)
+    if items is not None:
+        beams = np.ascontiguousarray(items[0], dtype=np.int32)
+        raynums = np.ascontiguousarray(items[1], dtype=np.int32)
+        steps = lib().cbet_oracle_trace_cbet_list(
+            C.byref(cfg), C.byref(g), np.ascontiguousarray(beam_norm, dtype=np.float64),
+            np.ascontiguousarray(ne3d, dtype=np.float64), np.ascontiguousarray(kap3d, dtype=np.float64), gp, quantity,
+            1 if per_beam else 0, len(beams), beams, raynums, out, beam_gain.ctypes.data_as(C.c_void_p), nthreads)
+        return out, int(steps), beam_gain
     steps = lib().cbet_oracle_trace_cbet(C.byref(cfg), C.byref(g), np.ascontiguousarray(beam_norm, dtype=np.float64),
                                          np.ascontiguousarray(ne3d, dtype=np.float64),
                                          np.ascontiguousarray(kap3d, dtype=np.float64), gp, quantity,

@@ -1,0 +1,36 @@
+"""Convergence history of the CBET fixed-point iteration for a few under-relaxation factors.
+usage: python scripts/cbet_converge.py [n=128] [nbeams=60] [relax,relax,...] [passes=30]"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cbet_raytracing_3d_amd import api
+from cbet_raytracing_3d_amd.tracer import RayTracer
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+nb = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+relaxes = [float(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1.0, 0.5, 0.25]
+passes = int(sys.argv[4]) if len(sys.argv) > 4 else 30
+r, ne, te = api.load_s83177()
+tr = RayTracer(api.default_params(n, nbeams=nb), r, ne, te)
+tr.tabulate()
+fields, gain = tr.new_fields(), tr.new_grid(per_beam=True)
+change = torch.zeros(2, dtype=torch.float64, device="cuda")
+bg = torch.zeros(nb, dtype=torch.float64, device="cuda")
+e = tr.new_grid()
+for relax in relaxes:
+    gp = api.default_gain_params(relax=relax)
+    gain.zero_()
+    hist = []
+    for it in range(passes):
+        fields.zero_()
+        for q in (1, 2, 3, 4):
+            tr.launch_cbet(fields[q - 1], gp, quantity=q, gain=gain if it else None)
+        change.zero_()
+        tr.gain_field(fields, gain, gp, change)
+        ch = change.cpu().numpy()
+        bg.zero_(); e.zero_()
+        tr.launch_cbet(e, gp, quantity=0, gain=gain, beam_gain=bg)
+        b = bg.cpu().numpy()
+        hist.append((ch[0] / ch[1], abs(b.sum()) / np.abs(b).sum(), float(gain.abs().max())))
+    print("relax %.2f" % relax)
+    for it, h in enumerate(hist):
+        print("  pass %2d change %.3e imbalance %.3e Kmax %.4g" % (it, *h))

@@ -32,7 +32,8 @@ def test_library_exports_every_declared_symbol(api):
 def test_struct_layout_matches_header(api, tmp_path):
     """ctypes mirrors vs the C header: sizeof and every field offset, asked of gcc."""
     import subprocess
-    probes = {"cbet_params": api.Params, "cbet_derived": api.Derived, "cbet_counters": api.Counters}
+    probes = {"cbet_params": api.Params, "cbet_derived": api.Derived, "cbet_counters": api.Counters,
+              "cbet_gain_params": api.GainParams, "cbet_cbet_report": api.CbetReport}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "cbet_mi355x.h"', 'int main(void){']
     for cname, cls in probes.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))

@@ -1,0 +1,213 @@
+"""The CBET stage off the GPU: the CPU restatement of the model, the host side of the
+C ABI, and the multi-rank loop over gloo.
+
+PARITY UNPINNED -- the reference has no CBET code (def.cuh:94-114: unused constants only).  What can be
+checked is what the model promises: hooks off = the reference ray loop, exact pairwise antisymmetry of
+the exchange, energy conservation in the linear limit and at the fixed point, and that sharding the
+iteration over ranks changes nothing.
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import NCPU, ROOT, load_inputs, parity_err
+
+N, BEAMS = 24, [0, 16, 38, 55]
+
+
+@pytest.fixture(scope="module")
+def api():
+    from cbet_raytracing_3d_amd import api as a
+    a.lib()
+    return a
+
+
+@pytest.fixture(scope="module")
+def case(oracle, inputs):
+    bn, r, ne, te = inputs
+    cfg = oracle.default_config(N, nbeams=len(BEAMS))
+    ne3d, kap = oracle.node_tables(cfg, r, ne, te)
+    g = oracle.gain_default()
+    b = bn[BEAMS].copy()
+    fields = np.stack([oracle.trace_cbet(cfg, g, b, ne3d, kap, quantity=q, per_beam=True, nthreads=NCPU)[0]
+                       for q in (1, 2, 3, 4)])
+    gain, change = oracle.gain_field(cfg, g, fields, ne3d, relax=1.0, nthreads=NCPU)
+    return dict(cfg=cfg, g=g, bn=b, ne3d=ne3d, kap=kap, fields=fields, gain=gain, change=change)
+
+
+def test_phi_is_expm1_over_x(oracle):
+    for x in np.concatenate([np.linspace(-1, 1, 41), [1e-12, -1e-9, 3e-5]]):
+        want = math.expm1(x) / x if x != 0 else 1.0
+        assert abs(oracle.phi(x) - want) <= 4e-16 * want
+    assert oracle.phi(0.0) == 1.0
+
+
+def test_hooks_off_is_the_pinned_ray_loop(oracle, case):
+    """quantity 0 without a gain field must be the node-table ray loop, bit for bit (serial order)."""
+    c = case
+    want, wsteps = oracle.trace_tables(c["cfg"], c["bn"], c["ne3d"], c["kap"], nthreads=1)
+    got, steps, bg = oracle.trace_cbet(c["cfg"], c["g"], c["bn"], c["ne3d"], c["kap"], nthreads=1)
+    assert steps == wsteps and np.array_equal(got, want) and not bg.any()
+    zero = np.zeros((len(BEAMS),) + got.shape)
+    got0, steps0, _ = oracle.trace_cbet(c["cfg"], c["g"], c["bn"], c["ne3d"], c["kap"], gain=zero, nthreads=1)
+    assert steps0 == wsteps and np.array_equal(got0, want)
+
+
+def test_fields_are_intensity_and_direction(oracle, case):
+    c, d = case, None
+    d = oracle.derive(case["cfg"])
+    E = c["fields"][0]
+    assert E.min() >= -1e-2 * E.max()   # the reference's deposit weights are not clamped: rare small negatives
+    peak = E.max() / (2.99792458e10 * d.dt)           # energy x length / step length ~ intensity, W/cm^2
+    assert 0.3e14 < peak < 4e14
+    # far from the target a beam still travels along its axis: the displacement field points along -beam_norm
+    for b in range(len(BEAMS)):
+        D = c["fields"][1:, b].reshape(3, -1)
+        tot = D.sum(axis=1)
+        cosang = -np.dot(tot / np.linalg.norm(tot), c["bn"][b] / np.linalg.norm(c["bn"][b]))
+        assert cosang > 0.9
+
+
+def test_exchange_is_pairwise_antisymmetric(case):
+    """sum_i I_i K_i = sum_ij I_i G_ij I_j = 0 in every cell (G_ij = -G_ji), to rounding."""
+    E, K = case["fields"][0], case["gain"]
+    assert np.abs(K).max() > 1.0
+    cell = (E * K).sum(axis=0)
+    assert np.abs(cell).max() <= 1e-12 * np.abs(E * K).sum(axis=0).max()
+    assert case["change"][0] == case["change"][1] > 0   # from zero: |new - old| = |new|
+
+
+def test_linear_limit_conserves_energy(oracle, case):
+    """With the gain scaled down, what the rays gain is sum_cells K x field, beam by beam, and the beams'
+    gains cancel to first order in the scale."""
+    c = case
+    for scale, bound in ((1e-2, 5e-2), (1e-3, 5e-3)):
+        _, _, bg = oracle.trace_cbet(c["cfg"], c["g"], c["bn"], c["ne3d"], c["kap"], gain=c["gain"] * scale, nthreads=NCPU)
+        assert np.abs(bg).max() > 0
+        assert abs(bg.sum()) / np.abs(bg).sum() < bound
+        field_level = (c["fields"][0] * c["gain"]).sum(axis=(1, 2, 3)) * scale
+        assert np.abs(bg - field_level).max() < 20 * scale * np.abs(field_level).max()
+
+
+def test_fixed_point_converges_and_conserves(oracle, case):
+    c = case
+    K, hist = None, []
+    for it in range(10):
+        F = np.stack([oracle.trace_cbet(c["cfg"], c["g"], c["bn"], c["ne3d"], c["kap"], gain=K, quantity=q,
+                                        per_beam=True, nthreads=NCPU)[0] for q in (1, 2, 3, 4)])
+        K, ch = oracle.gain_field(c["cfg"], c["g"], F, c["ne3d"], relax=1.0, gain=K, nthreads=NCPU)
+        hist.append(ch[0] / ch[1])
+        if hist[-1] < 1e-7:
+            break
+    assert hist[-1] < 1e-7 and hist[-1] < hist[1] < hist[0]
+    e, steps, bg = oracle.trace_cbet(c["cfg"], c["g"], c["bn"], c["ne3d"], c["kap"], gain=K, nthreads=NCPU)
+    assert np.abs(bg).max() > 1e11
+    assert abs(bg.sum()) / np.abs(bg).sum() < 1e-5      # what beams gain and lose cancels at the fixed point
+    e0, _ = oracle.trace_tables(c["cfg"], c["bn"], c["ne3d"], c["kap"], nthreads=NCPU)
+    assert 0.9 < e.sum() / e0.sum() < 1.1 and parity_err(e, e0) > 1e-3
+
+
+def test_gain_params_and_constants_host_side(api, oracle, case):
+    g = api.default_gain_params()
+    og = case["g"]
+    for name in ("z_ion", "te_ev", "ti_ev", "mi_over_me", "iaw", "mach_r0", "mach_0", "mach_r1", "mach_1", "max_exponent"):
+        assert getattr(g, name) == getattr(og, name), name
+    assert (g.relax, g.tolerance, g.max_passes) == (0.5, 1e-4, 40)
+    p = api.default_params(N, nbeams=len(BEAMS))
+    c1, cs, gc = api.gain_constants(p, g)
+    assert (c1, cs, gc) == oracle.gain_constants(case["cfg"], og)
+    assert 3.9e7 < cs < 4.1e7                           # def.cuh:113 "approx. 4e7 cm/s in this example"
+    assert api.cbet_workspace_bytes(p) == (5 * len(BEAMS) * (N + 2) ** 3 + 2 + api.MAX_CBET_BEAMS) * 8
+    for bad in (dict(max_exponent=0.0), dict(max_exponent=1.5), dict(relax=0.0), dict(relax=1.01), dict(iaw=0.0),
+                dict(mach_r1=0.01)):
+        with pytest.raises(api.CbetError) as ei:
+            api.gain_constants(p, api.default_gain_params(**bad))
+        assert ei.value.code == api.EINVAL
+    with pytest.raises(api.CbetError) as ei:
+        api.gain_constants(api.default_params(N, nbeams=65), g)
+    assert ei.value.code == api.EINVAL
+
+
+class _OracleEngine:
+    """cbet_fixed_point's per-rank compute with the oracle standing in for the device."""
+
+    def __init__(self, O, api, cfg, g, bn, ne3d, kap, nbeams):
+        self.O, self.api, self.cfg, self.g, self.bn, self.ne3d, self.kap, self.nb = O, api, cfg, g, bn, ne3d, kap, nbeams
+        self.p = api.default_params(cfg.nx, nbeams=nbeams)
+        self.gain = None
+        self.edep = np.zeros(O.grid_shape(cfg))
+        self.steps = 0
+
+    def begin(self):
+        self.gain = np.zeros((self.nb,) + self.O.grid_shape(self.cfg))
+
+    def _items(self, si, sc):
+        return self.api.shard_items(self.p, self.nb, si, sc)
+
+    def field_passes(self, use_gain, si, sc):
+        F = [self.O.trace_cbet(self.cfg, self.g, self.bn, self.ne3d, self.kap, gain=self.gain if use_gain else None,
+                               quantity=q, per_beam=True, nthreads=2, items=self._items(si, sc))[0] for q in (1, 2, 3, 4)]
+        return torch.from_numpy(np.stack(F))
+
+    def update_gain(self, fields):
+        self.gain, ch = self.O.gain_field(self.cfg, self.g, fields.numpy(), self.ne3d, relax=1.0, gain=self.gain, nthreads=2)
+        return torch.tensor(ch, dtype=torch.float64)
+
+    def deposit(self, si, sc):
+        e, steps, bg = self.O.trace_cbet(self.cfg, self.g, self.bn, self.ne3d, self.kap, gain=self.gain, nthreads=2,
+                                         items=self._items(si, sc))
+        self.edep += e
+        self.steps = steps
+        return torch.from_numpy(bg)
+
+
+def _solve(rank, world, group=None):
+    sys.path.insert(0, ROOT)
+    from cbet_raytracing_3d_amd import api
+    from cbet_raytracing_3d_amd.tracer import allreduce_grid, cbet_fixed_point
+    from oracle import cbet_oracle as O
+    bn, r, ne, te = load_inputs()
+    cfg = O.default_config(N, nbeams=len(BEAMS))
+    ne3d, kap = O.node_tables(cfg, r, ne, te)
+    eng = _OracleEngine(O, api, cfg, O.gain_default(), bn[BEAMS].copy(), ne3d, kap, len(BEAMS))
+    gp = api.default_gain_params(relax=1.0, tolerance=1e-5, max_passes=8)
+    rep = cbet_fixed_point(eng, gp, rank, world, group)
+    edep = torch.from_numpy(eng.edep)
+    allreduce_grid(edep, group)
+    steps = torch.tensor([eng.steps], dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(steps)
+    return rep, edep.numpy(), int(steps[0]), eng.gain
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rep, edep, steps, gain = _solve(rank, world)
+        if rank == 0:
+            np.savez(os.path.join(out_dir, "out.npz"), edep=edep, steps=steps, gain=gain, passes=rep["passes"],
+                     converged=rep["converged"], beam_gain=rep["beam_gain"], imbalance=rep["imbalance"])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_iteration_equals_unsharded(tmp_path, api, oracle):
+    """world_size-2 gloo: the loop GPU ranks run over RCCL (tracer.cbet_fixed_point: shard the bundles,
+    all-reduce the fields every pass, all-reduce the energy balance) against the single-rank result."""
+    port = 29600 + (os.getpid() % 300)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / "out.npz")
+    rep, edep, steps, gain = _solve(0, 1)
+    assert rep["converged"] and bool(got["converged"]) and int(got["passes"]) == rep["passes"]
+    assert int(got["steps"]) == steps
+    assert parity_err(got["edep"], edep) < 1e-9
+    assert np.abs(got["gain"] - gain).max() < 1e-9 * np.abs(gain).max()
+    assert np.abs(got["beam_gain"] - rep["beam_gain"]).max() < 1e-9 * np.abs(rep["beam_gain"]).max()
+    assert float(got["imbalance"]) < 1e-3 and rep["imbalance"] < 1e-3

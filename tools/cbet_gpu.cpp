@@ -1,9 +1,10 @@
 // cbet-gpu -- run-time-configured driver with the reference's command line and stdout contract
 // (/root/reference/main.cu:234-357):
-//     cbet-gpu [omp_threads] [--n N] [--gpus G] [--beams B] [--print] [--data DIR]
+//     cbet-gpu [omp_threads] [--n N] [--gpus G] [--beams B] [--print] [--data DIR] [--cbet]
 // Without --print it prints the four phase timers in main.cu:225-230's format; with --print it
 // writes the -D PRINT text rendering of edep to stdout (what `make test` compares with truth_100).
-// Links only against the C ABI (libcbet_mi355x.so).
+// --cbet runs the CBET fixed-point iteration (cbet_cbet_solve; parity unpinned, no reference counterpart) on
+// device 0 instead of the single reference pass.  Links only against the C ABI (libcbet_mi355x.so).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -15,7 +16,7 @@
 int main(int argc, char **argv)
 {
     int n = 100, gpus = 1, beams = 60;
-    bool print = false;
+    bool print = false, cbet = false;
     std::string data = "cbet_raytracing_3d_amd/data";
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -24,8 +25,9 @@ int main(int argc, char **argv)
         else if (a == "--beams" && i + 1 < argc) beams = std::atoi(argv[++i]);
         else if (a == "--data" && i + 1 < argc) data = argv[++i];
         else if (a == "--print") print = true;
+        else if (a == "--cbet") cbet = true;
         else if (i == 1 && std::atoi(argv[1]) > 0) { /* argv[1] = OpenMP threads in the reference (main.cu:236-242); no host loops here */ }
-        else { std::fprintf(stderr, "usage: %s [omp_threads] [--n N] [--gpus G] [--beams B] [--print] [--data DIR]\n", argv[0]); return 2; }
+        else { std::fprintf(stderr, "usage: %s [omp_threads] [--n N] [--gpus G] [--beams B] [--print] [--data DIR] [--cbet]\n", argv[0]); return 2; }
     }
     cbet_params p;
     cbet_params_default(&p, n);
@@ -41,6 +43,40 @@ int main(int argc, char **argv)
         return 1;
     }
     std::vector<double> edep((size_t)d.edep_size, 0.0);  // main.cu:262
+    if (cbet) {
+        // the allocation / upload sequence of main.cu:136-151 through the same two helpers, then the iteration
+        std::vector<double> phase_r(CBET_NPHASE), pow_r(CBET_NPHASE), bbeam(4 * (size_t)beams);
+        const double *bn = cbet_omega60_beam_norm();
+        cbet_host_power_table(phase_r.data(), pow_r.data());
+        cbet_host_beam_trig(bn, beams, bbeam.data());
+        struct Buf { void *d; const void *h; size_t bytes; } bufs[] = {
+            {nullptr, te.data(), te.size() * 8}, {nullptr, r.data(), r.size() * 8}, {nullptr, ne.data(), ne.size() * 8},
+            {nullptr, edep.data(), edep.size() * 8}, {nullptr, bbeam.data(), bbeam.size() * 8},
+            {nullptr, bn, 3 * (size_t)beams * 8}, {nullptr, pow_r.data(), pow_r.size() * 8},
+            {nullptr, phase_r.data(), phase_r.size() * 8}};
+        for (auto &b : bufs)
+            if (cbet_safeGPUAlloc(&b.d, b.bytes, 0) != CBET_OK || cbet_moveToAndFromGPU(b.d, (void *)b.h, b.bytes, 0) != CBET_OK) {
+                std::fprintf(stderr, "%s\n", cbet_last_error());
+                return 1;
+            }
+        cbet_gain_params g;
+        cbet_gain_params_default(&g);
+        cbet_cbet_report rep;
+        if (cbet_cbet_solve((double *)bufs[0].d, (double *)bufs[1].d, (double *)bufs[2].d, (double *)bufs[3].d,
+                            (double *)bufs[4].d, (double *)bufs[5].d, (double *)bufs[6].d, (double *)bufs[7].d, &p, &g,
+                            nullptr, nullptr, nullptr, &rep) != CBET_OK ||
+            cbet_moveToAndFromGPU(edep.data(), bufs[3].d, bufs[3].bytes, 0) != CBET_OK) {
+            std::fprintf(stderr, "%s\n", cbet_last_error());
+            return 1;
+        }
+        for (auto &b : bufs) cbet_gpuFree(b.d, 0);
+        if (print) return cbet_write_text(edep.data(), p.nx + 2, p.ny + 2, p.nz + 2, nullptr) < 0;
+        double sum = 0;
+        for (double v : edep) sum += v;
+        std::printf("cbet: passes %d converged %d gain-change %.3e energy-imbalance %.3e\nray-steps %llu (final pass %llu)  sum(edep) %.10e\n",
+                    rep.passes, rep.converged, rep.change, rep.imbalance, rep.ray_steps, rep.ray_steps_final, sum);
+        return 0;
+    }
     double t[4];
     cbet_counters cnt;
     if (cbet_ray_tracing(te.data(), r.data(), ne.data(), edep.data(), &p, nullptr, nullptr, gpus, t, &cnt) != CBET_OK) {
