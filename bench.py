@@ -69,7 +69,7 @@ def cbet_leg(api, tr, edep, n):
             "passes": rep.passes, "converged": bool(rep.converged), "gain_change": rep.change,
             "energy_imbalance": rep.imbalance, "seconds": dt,
             "ray_steps_traced": int(rep.ray_steps), "ray_steps_per_s": rep.ray_steps / dt,
-            "launches_per_pass": 4, "ray_steps_final_pass": int(rep.ray_steps_final),
+            "traces_per_pass": 1, "ray_steps_final_pass": int(rep.ray_steps_final),
             "absorbed_sum": absorbed, "max_beam_gain_over_mean_absorbed": float(np.abs(bg).max() / (absorbed / len(bg))),
             "relax": gp.relax, "tolerance": gp.tolerance}
 

@@ -82,6 +82,7 @@ class Counters(C.Structure):
 
 
 MAX_CBET_BEAMS = 64
+DEPOSIT_ENERGY, DEPOSIT_FIELDS = 0, 1   # cbet_trace_cbet's `quantity`
 
 
 class GainParams(C.Structure):

@@ -586,7 +586,8 @@ static int trace_impl(int b, unsigned nindices, const double *ne3d, const double
     a.kap3d = kappa3d ? kappa3d : ctx->kap3d;
     a.beam_norm = beam_norm; a.bbeam_norm = bbeam_norm; a.pow_r = pow_r; a.phase_r = phase_r;
     a.edep = edep;
-    a.grid_stride = p->per_beam_grids ? d.edep_size : 0;
+    a.grid_stride = (p->per_beam_grids || hooks.quantity != 0) ? d.edep_size : 0;  // field passes are always beam-resolved
+    a.comp_stride = (long)p->nbeams * d.edep_size;
     a.counters = ctx->counters;
     a.gain = hooks.gain; a.hsize = d.edep_size; a.quantity = hooks.quantity;
     a.max_exponent = hooks.max_exponent; a.beam_gain = hooks.beam_gain;
@@ -713,7 +714,8 @@ int cbet_trace_cbet(int b, unsigned nindices, const double *ne3d, const double *
 {
     if (int rc = validate(p)) return rc;
     if (int rc = validate_gain(p, g)) return rc;
-    if (quantity < 0 || quantity > 4) return fail(CBET_EINVAL, "quantity must be 0..4");
+    if (quantity != CBET_DEPOSIT_ENERGY && quantity != CBET_DEPOSIT_FIELDS)
+        return fail(CBET_EINVAL, "quantity must be CBET_DEPOSIT_ENERGY (0) or CBET_DEPOSIT_FIELDS (1)");
     CbetHooks h;
     h.gain = gain; h.quantity = quantity; h.beam_gain = beam_gain; h.max_exponent = g->max_exponent;
     return trace_impl(b, nindices, ne3d, kappa3d, out, bbeam_norm, beam_norm, pow_r, phase_r, xconst, yconst, zconst,
@@ -742,7 +744,6 @@ int cbet_gain_field(double *fields, const double *ne3d, double *gain, double *ch
     a.fields = fields; a.ne3d = ne3d ? ne3d : ctx->ne3d; a.gain = gain; a.change = change;
     DeviceGuard guard;
     CBET_HIP(hipSetDevice(ctx->gpu));
-    CBET_HIP(launch_field_normalize(a, (hipStream_t)stream));
     CBET_HIP(launch_gain_field(a, (hipStream_t)stream));
     return CBET_OK;
 }
@@ -790,17 +791,17 @@ int cbet_cbet_solve(double *te_data_g, double *r_data_g, double *ne_data_g, doub
         if (int r = cbet_tabulate_plasma(ctx, p, te_data_g, r_data_g, ne_data_g, stream)) return r;
         if (int r = cbet_context_counters(ctx, stream, &c0, 0)) return r;
         CBET_HIP(hipMemsetAsync(gain, 0, nb * hsize * sizeof(double), s));
-        cbet_params pf = *p;            // field passes: beam-resolved grids, every beam
-        pf.per_beam_grids = 1; pf.beam_lo = 0; pf.beam_hi = p->nbeams;
+        cbet_params pf = *p;            // field passes: every beam (always beam-resolved)
+        pf.beam_lo = 0; pf.beam_hi = p->nbeams;
         cbet_params pd = *p;            // deposition pass: the caller's grid layout, every beam
         pd.beam_lo = 0; pd.beam_hi = p->nbeams;
         for (int pass = 0; pass < g->max_passes; ++pass) {
             CBET_HIP(hipMemsetAsync(fields, 0, 4 * nb * hsize * sizeof(double), s));
-            for (int q = 1; q <= 4; ++q) {
+            {
                 CbetHooks h;
-                h.gain = pass == 0 ? nullptr : gain; h.quantity = q; h.max_exponent = g->max_exponent;
-                if (int r = trace_impl(0, (unsigned)d.nindices, nullptr, nullptr, fields + (size_t)(q - 1) * nb * hsize, bbeam_norm,
-                                       beam_norm, pow_r, phase_r, d.xconst, d.yconst, d.zconst, &pf, ctx, stream, h))
+                h.gain = pass == 0 ? nullptr : gain; h.quantity = CBET_DEPOSIT_FIELDS; h.max_exponent = g->max_exponent;
+                if (int r = trace_impl(0, (unsigned)d.nindices, nullptr, nullptr, fields, bbeam_norm, beam_norm, pow_r, phase_r,
+                                       d.xconst, d.yconst, d.zconst, &pf, ctx, stream, h))
                     return r;
             }
             CBET_HIP(hipMemsetAsync(change, 0, 2 * sizeof(double), s));

@@ -73,12 +73,13 @@ struct TraceArgs {
     // CBET extension (no reference counterpart).  All zero / NULL = the reference path.
     const double *gain;                     // [nbeams][(n+2)^3] gain coefficient on the deposit grid, 1/cm
     long hsize;                             // (nx+2)(ny+2)(nz+2)
-    int quantity;                           // deposited scalar: 0 absorbed energy, 1 energy x path length, 2..4 energy x displacement
+    int quantity;                           // 0: deposit the absorbed energy; 1: the four field components (fused field pass)
+    long comp_stride;                       // field pass: doubles between the component arrays (nbeams * hsize)
     double max_exponent;                    // clamp on |K ds| per step (<= 1)
     double *beam_gain;                      // [nbeams] energy gained through CBET, or NULL
 };
 
-// Field normalisation + gain coefficient kernels (CBET extension).
+// Field normalisation + gain coefficient kernel (CBET extension).
 struct GainArgs {
     int nx, ny, nz, nbeams;
     double xmin, ymin, zmin, dx, dy, dz, dt;
@@ -86,7 +87,7 @@ struct GainArgs {
     double cs, gain_const, iaw;
     double mach_r0, mach_0, mach_r1, mach_1;
     double relax;
-    double *fields;                         // [4][nbeams][hsize]: (E, Dx, Dy, Dz) in, (I, kx, ky, kz) out
+    double *fields;                         // [4][nbeams][hsize]: (E, Dx, Dy, Dz) in; (I, kx, ky, kz) out where the beam is present
     const double *ne3d;                     // [nx*ny*nz]
     double *gain;                           // [nbeams][hsize]
     double *change;                         // device {sum |new-old|, sum |new|} accumulators, or NULL
@@ -96,7 +97,6 @@ hipError_t launch_tabulate(const TabulateArgs &a, hipStream_t stream);
 hipError_t audit_violations(unsigned long long *out, bool reset, hipStream_t stream);
 hipError_t launch_trace(const TraceArgs &a, int variant, int window_log2, int copies_log2, int prereduce,
                         bool corner_flip, bool two_boxes, bool force_idx64, hipStream_t stream);
-hipError_t launch_field_normalize(const GainArgs &a, hipStream_t stream);
 hipError_t launch_gain_field(const GainArgs &a, hipStream_t stream);
 
 }  // namespace cbet

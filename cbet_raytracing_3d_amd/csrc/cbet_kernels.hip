@@ -353,7 +353,7 @@ __device__ __forceinline__ void lds_deposit8(LdsWindow<WL> &win, bool pending, c
 // deposits straight to HBM for that step.  Everything is lock-step within one wave (one wave per
 // workgroup), so the origin, the shifts and the slab loops are scalar.
 // ---------------------------------------------------------------------------------------------
-template <int WL, int RL>
+template <int WL, int RL, int NC = 1>
 struct MovingWindow {
     static constexpr int W = 1 << WL;
     static constexpr int R = 1 << RL;     // privatised copies of the tile, selected by lane & (R-1)
@@ -369,6 +369,11 @@ struct MovingWindow {
     static constexpr int NDOUBLES = R * CS;
     double *val;                          // NDOUBLES accumulators
     int ox, oy, oz;
+    // NC > 1 (CBET field pass): NC - 1 further tiles of the same geometry, `cstride` doubles apart in
+    // LDS, flushed to grids `gstride` doubles apart in HBM (components 1.. are never deferred)
+    int limit;                            // doubles addressable from val (all boxes' and components' tiles)
+    int cstride;
+    long gstride;
 
     static __device__ __forceinline__ int addr(int rx, int ry, int rz) { return rx * XS + ry * YS + rz; }
 
@@ -404,8 +409,19 @@ struct MovingWindow {
             double v = val[slot];
 #pragma unroll
             for (int c = 1; c < R; ++c) v += val[c * CS + slot];
+            const int node = i * sXh + j * sYh + k;
+            if (NC > 1) {
+#pragma unroll
+                for (int q = 1; q < NC; ++q) {
+                    const double vq = val[q * cstride + slot];
+                    if (vq != 0.0) {
+                        global_add(&edep[q * gstride + node], vq);
+                        val[q * cstride + slot] = 0.0;
+                        ++n_at;
+                    }
+                }
+            }
             if (v != 0.0) {  // only nodes that received deposits are non-zero, hence valid
-                const int node = i * sXh + j * sYh + k;
                 if (DEFER && W * W == kWave) {
                     dv = v;
                     dn = node;
@@ -459,7 +475,6 @@ struct MovingWindow {
         int dn = 0;
         for (int t = 0; t < W; ++t) retire<0, false>(ox + t, lane, edep, sXh, sYh, n_at, dv, dn);
     }
-    int limit;  // doubles addressable from val (both boxes' tiles when there are two)
     __device__ __forceinline__ void add(int slot, double w)
     {
         if (CBET_AUDIT((unsigned)slot < (unsigned)limit))
@@ -547,16 +562,21 @@ __device__ __forceinline__ double phi_det(double x)
     return p;
 }
 
-// CBET = true adds the cross-beam-energy-transfer hooks (no reference counterpart):
-// gain gathered from the eight deposit nodes, ray energy x exp(K ds), selectable deposited quantity.
-template <int DEPOSIT, int WL, int RL, int PRE, bool FLIP, bool TWOBOX, bool IDX64, bool ABSORB, bool CBET = false>
+// CBET != 0 adds the cross-beam-energy-transfer hooks (no reference counterpart): the
+// gain coefficient gathered from the eight deposit nodes, ray energy x exp(K ds), and
+//   CBET = 1: the deposit is the absorbed energy, as in the reference path;
+//   CBET = 4: the field pass -- FOUR grids per beam in one trace: energy x path length with the eight
+//             deposit weights (component 0) and energy x displacement x/y/z at the ray's own node
+//             (components 1..3), each component in its own LDS tile of the moving window.
+template <int DEPOSIT, int WL, int RL, int PRE, bool FLIP, bool TWOBOX, bool IDX64, bool ABSORB, int CBET = 0>
 __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
 {
+    constexpr int NC = (CBET == 4) ? 4 : 1;
     constexpr int NSLOT = (DEPOSIT == 3) ? (TWOBOX ? 2 : 1) * MovingWindow<WL, RL>::NDOUBLES
                                          : (DEPOSIT == 2 ? (1 << (3 * WL)) : 1);
     constexpr int NTAG = (DEPOSIT == 2) ? NSLOT : 1;
     constexpr int W = 1 << WL;
-    __shared__ double s_val[NSLOT];
+    __shared__ double s_val[NSLOT * NC];
     __shared__ unsigned s_tag[NTAG];
     const int lane = threadIdx.x;
 #ifdef CBET_EXPERIMENT_EXTRA_LDS  // occupancy-sensitivity experiment builds only (scripts/experiment_occupancy.sh)
@@ -615,13 +635,13 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
     unsigned w_slabs_wide = 0;   // slabs retired << 16 | wave-steps "too wide" (two boxes: box B live)
 
     LdsWindow<WL> tagged{s_val, s_tag};
-    MovingWindow<WL, RL> win{s_val, 0, 0, 0, NSLOT};
+    MovingWindow<WL, RL, NC> win{s_val, 0, 0, 0, NSLOT * NC, NSLOT, a.comp_stride};
     // Second box (TWOBOX): after the turning point a bundle fans out to 6-11 cells (scripts/
     // bundle_spread.py), wider than one 8-cell box.  Lanes that fall out of box A are adopted by
     // box B (sticky per-lane home bit); B is created around the first such lane and flushed when
     // its last lane leaves or dies.
-    MovingWindow<WL, RL> winB{s_val + (TWOBOX ? MovingWindow<WL, RL>::NDOUBLES : 0), 0, 0, 0,
-                              MovingWindow<WL, RL>::NDOUBLES};
+    MovingWindow<WL, RL, NC> winB{s_val + (TWOBOX ? MovingWindow<WL, RL>::NDOUBLES : 0), 0, 0, 0,
+                                  MovingWindow<WL, RL>::NDOUBLES, NSLOT, a.comp_stride};
     bool homeB = false;     // per lane
     bool b_active = false;  // wave-uniform
 
@@ -636,6 +656,8 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
         win.init(lane, __builtin_amdgcn_readlane(s.ci, src) + 1, __builtin_amdgcn_readlane(s.cj, src) + 1,
                  __builtin_amdgcn_readlane(s.ck, src) + 1);
         if (TWOBOX) winB.init(lane, 0, 0, 0);
+        if (NC > 1)
+            for (int z = NSLOT + lane; z < NSLOT * NC; z += kWave) s_val[z] = 0.0;  // the further components' tiles
         __syncthreads();
     }
 
@@ -678,7 +700,7 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
     if (alive) gather_stencil();
     const double *const gk = CBET && a.gain ? a.gain + (long)beam * a.hsize : nullptr;  // this beam's gain grid
     double gained = 0.0;                     // CBET: energy this lane's ray gained
-    double q_dep = 0.0;                      // CBET: the field quantity this step deposits
+    double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;  // CBET = 4: the four field quantities this step deposits
     double dv0 = 0.0, dv1 = 0.0, dv2 = 0.0;  // deferred slab sums (one per axis) and their nodes
     int dn0 = 0, dn1 = 0, dn2 = 0;
     unsigned slabs_seen = 0;                 // wave-uniform: value of the slab counter when last drained
@@ -806,7 +828,7 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
             if (CBET) {
                 // path length of the step; u_eff = the ray's energy averaged over the step
                 double ds = 0.0;
-                if (gk || a.quantity == 1) ds = sqrt(s.vx * s.vx + s.vy * s.vy + s.vz * s.vz) * a.dt;
+                if (gk || CBET == 4) ds = sqrt(s.vx * s.vx + s.vy * s.vy + s.vz * s.vz) * a.dt;
                 double u_eff = s.uray;
                 if (gk) {
                     // K at the eight deposit nodes, weighted like the deposit.  The pairwise tree makes the
@@ -827,10 +849,12 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
                     gained += dg;
                     s.uray = s.uray + dg;
                 }
-                if (a.quantity == 1) q_dep = u_eff * ds;
-                else if (a.quantity == 2) q_dep = u_eff * (s.vx * a.dt);
-                else if (a.quantity == 3) q_dep = u_eff * (s.vy * a.dt);
-                else if (a.quantity == 4) q_dep = u_eff * (s.vz * a.dt);
+                if (CBET == 4) {
+                    q0 = u_eff * ds;
+                    q1 = u_eff * (s.vx * a.dt);
+                    q2 = u_eff * (s.vy * a.dt);
+                    q3 = u_eff * (s.vz * a.dt);
+                }
             }
             if (DEPOSIT != 3) {
 #pragma unroll
@@ -929,7 +953,7 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
                 } else {
                     inc = s.uray;
                 }
-                if (CBET && a.quantity != 0) inc = q_dep;
+                if (CBET == 4) inc = q0;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) wgt[c] = wgt[c] * inc;
             }
@@ -955,6 +979,12 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
                 win.add(x1 + y1 + z0, wgt[5]);
                 win.add(x0 + y1 + z1, wgt[6]);
                 win.add(x1 + y1 + z1, wgt[7]);
+                if (CBET == 4) {  // displacement components: the ray's own node only
+                    const int own = (hi & (W - 1)) * MW::XS + (hj & (W - 1)) * MW::YS + (hk & (W - 1)) + copy;
+                    win.add(own + NSLOT, q1);
+                    win.add(own + 2 * NSLOT, q2);
+                    win.add(own + 3 * NSLOT, q3);
+                }
             } else if (alive && !inbox) {
 #ifndef CBET_EXPERIMENT_DROP_MISS_ATOMICS  // timing-only experiment builds; never shipped
                 const int nX0 = __mul24(X0, sXh), nX1 = __mul24(X1, sXh), nY0 = __mul24(Y0, sYh), nY1 = __mul24(Y1, sYh);
@@ -966,6 +996,13 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
                 global_add(&edep[nX1 + nY1 + Z0], wgt[5]);
                 global_add(&edep[nX0 + nY1 + Z1], wgt[6]);
                 global_add(&edep[nX1 + nY1 + Z1], wgt[7]);
+                if (CBET == 4) {
+                    const int own = __mul24(hi, sXh) + __mul24(hj, sYh) + hk;
+                    global_add(&edep[a.comp_stride + own], q1);
+                    global_add(&edep[2 * a.comp_stride + own], q2);
+                    global_add(&edep[3 * a.comp_stride + own], q3);
+                    n_atomics += 3;
+                }
 #endif
                 n_atomics += 8;
                 ++n_evict;  // counted as "ray-steps that missed the window"
@@ -1062,73 +1099,75 @@ __device__ __forceinline__ CellState cell_state(const GainArgs &a, long h)
     return c;
 }
 
-// In place: (E, Dx, Dy, Dz) -> (I, kx, ky, kz) per beam and cell; a beam that is absent from a cell
-// (no energy, no direction, or an over-critical cell) gets I = 0.  One thread per (beam, cell).
-__global__ void __launch_bounds__(256) k_field_normalize(const GainArgs a)
-{
-    const long hsize = (long)(a.nx + 2) * (a.ny + 2) * (a.nz + 2);
-    const long total = hsize * a.nbeams;
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
-        const long h = idx % hsize;
-        double *f0 = a.fields + idx, *f1 = f0 + total, *f2 = f1 + total, *f3 = f2 + total;
-        const double E = *f0, ax = *f1, ay = *f2, az = *f3;
-        const CellState c = cell_state(a, h);
-        const double dn = sqrt(ax * ax + ay * ay + az * az);
-        double I = 0.0, kx = 0.0, ky = 0.0, kz = 0.0;
-        if (c.eps > 0.0 && E > 0.0 && dn > 0.0) {
-            const double kmag = a.k0 * c.rt;
-            const double ds_node = (kC * c.rt) * a.dt;  // group speed x dt: energy x length -> intensity
-            I = E / ds_node;
-            kx = kmag * (ax / dn);
-            ky = kmag * (ay / dn);
-            kz = kmag * (az / dn);
-        }
-        *f0 = I; *f1 = kx; *f2 = ky; *f3 = kz;
-    }
-}
-
-// K_i(cell) = sum_{j != i} G_ij I_j over the beams present in the cell, then under-relaxation into
-// `gain`.  One thread per cell (consecutive lanes = consecutive z cells: every load below is a
-// coalesced 512-B row of one beam's grid); the beam loops run over the beams present ANYWHERE in the
-// wave's 64 cells (a ballot-built bit mask), so empty beams cost nothing.
+// fields (E, Dx, Dy, Dz) -> gain coefficient, one wavefront per 2 x 4 x 8 brick of deposit-grid cells
+// (z fastest: every load is eight 64-B runs).  A compact brick keeps the set of beams present
+// ANYWHERE in the wave small -- the beam loops below run over that set (a ballot-built bit mask),
+// and a 64-cell z-row crosses several times more beams than a brick does.
+//   phase 1: for every beam present in a lane's cell, normalise in place to (I, kx, ky, kz);
+//            entries of absent beams (E <= 0) are left as deposited and never used.
+//   phase 2: K_i = sum_{j != i} G_ij I_j, beams in increasing order; gain <- gain + relax (K - gain),
+//            stored only where it changes.
 __global__ void __launch_bounds__(256) k_gain_field(const GainArgs a)
 {
-    const long hsize = (long)(a.nx + 2) * (a.ny + 2) * (a.nz + 2);
+    const int HX = a.nx + 2, HY = a.ny + 2, HZ = a.nz + 2;
+    const long hsize = (long)HX * HY * HZ;
     const long total = hsize * a.nbeams;
+    const int bx = (HX + 1) / 2, by = (HY + 3) / 4, bz = (HZ + 7) / 8;
+    const long bricks = (long)bx * by * bz;
+    const int lane = threadIdx.x & (kWave - 1);
+    const long wave0 = (long)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    const long nwaves = (long)gridDim.x * (blockDim.x / kWave);
     const double iaw2 = a.iaw * a.iaw;
-    const long stride = (long)gridDim.x * blockDim.x;
     double sum_change = 0.0, sum_abs = 0.0;
-    const long rounds = (hsize + stride - 1) / stride;  // every thread runs the same number of rounds: ballots stay wave-wide
-    for (long rd = 0; rd < rounds; ++rd) {
-        const long h0 = rd * stride + (long)blockIdx.x * blockDim.x + threadIdx.x;
-        const bool valid = h0 < hsize;
-        const long h = valid ? h0 : hsize - 1;
-        const double *fI = a.fields + h, *fx = fI + total, *fy = fx + total, *fz = fy + total;
-        unsigned long long mask = 0ull;  // beams present in some cell of this wave
-        for (int b = 0; b < a.nbeams; ++b)
-            if (__builtin_amdgcn_ballot_w64(valid && fI[(long)b * hsize] > 0.0) != 0ull) mask |= 1ull << b;
-        double pref = 0.0, ux = 0.0, uy = 0.0, uz = 0.0;
-        if (mask != 0ull) {
-            const CellState c = cell_state(a, h);
-            if (c.eps > 0.0) pref = a.gain_const * c.frac * (1.0 / a.iaw) / c.rt;
-            ux = c.ux; uy = c.uy; uz = c.uz;
+    for (long brick = wave0; brick < bricks; brick += nwaves) {
+        const int ibz = (int)(brick % bz);
+        const long t = brick / bz;
+        const int iby = (int)(t % by), ibx = (int)(t / by);
+        const int hi = 2 * ibx + (lane >> 5), hj = 4 * iby + ((lane >> 3) & 3), hk = 8 * ibz + (lane & 7);
+        const bool valid = hi < HX && hj < HY && hk < HZ;
+        const long h = valid ? ((long)hi * HY + hj) * HZ + hk : 0;
+        double *fI = a.fields + h, *fx = fI + total, *fy = fx + total, *fz = fy + total;
+        const CellState c = cell_state(a, h);
+        const double kmag = a.k0 * c.rt;
+        const double ds_node = (kC * c.rt) * a.dt;  // group speed x dt: energy x length -> intensity
+        unsigned long long mask = 0ull;             // beams present in some cell of this brick
+        for (int b = 0; b < a.nbeams; ++b) {
+            const long o = (long)b * hsize;
+            const double E = valid ? fI[o] : 0.0;
+            const bool pres = E > 0.0;
+            if (__builtin_amdgcn_ballot_w64(pres) == 0ull) continue;
+            mask |= 1ull << b;
+            if (pres) {
+                const double ax = fx[o], ay = fy[o], az = fz[o];
+                const double dn = sqrt(ax * ax + ay * ay + az * az);
+                double I = 0.0, kx = 0.0, ky = 0.0, kz = 0.0;
+                if (c.eps > 0.0 && dn > 0.0) {
+                    I = E / ds_node;
+                    kx = kmag * (ax / dn);
+                    ky = kmag * (ay / dn);
+                    kz = kmag * (az / dn);
+                }
+                fI[o] = I; fx[o] = kx; fy[o] = ky; fz[o] = kz;
+            }
         }
+        const double pref = c.eps > 0.0 ? a.gain_const * c.frac * (1.0 / a.iaw) / c.rt : 0.0;
         for (int bi = 0; bi < a.nbeams; ++bi) {
+            const long oi = (long)bi * hsize;
             double raw = 0.0;
             if ((mask >> bi) & 1ull) {
-                const double Ii = fI[(long)bi * hsize];
-                const double kxi = fx[(long)bi * hsize], kyi = fy[(long)bi * hsize], kzi = fz[(long)bi * hsize];
+                const double Ii = fI[oi];
+                const double kxi = fx[oi], kyi = fy[oi], kzi = fz[oi];
                 double acc = 0.0;
                 unsigned long long m = mask & ~(1ull << bi);
                 while (m != 0ull) {
                     const int bj = __ffsll((long long)m) - 1;
                     m &= m - 1;
-                    const double Ij = fI[(long)bj * hsize];
-                    const double qx = fx[(long)bj * hsize] - kxi, qy = fy[(long)bj * hsize] - kyi, qz = fz[(long)bj * hsize] - kzi;
+                    const long oj = (long)bj * hsize;
+                    const double Ij = fI[oj];
+                    const double qx = fx[oj] - kxi, qy = fy[oj] - kyi, qz = fz[oj] - kzi;
                     const double kiaw = sqrt(qx * qx + qy * qy + qz * qz);
-                    if (Ii > 0.0 && Ij > 0.0 && kiaw > 0.0) {
-                        const double eta = (0.0 - (qx * ux + qy * uy + qz * uz)) / (kiaw * a.cs + 1e-10);
+                    if (valid && Ii > 0.0 && Ij > 0.0 && kiaw > 0.0) {
+                        const double eta = (0.0 - (qx * c.ux + qy * c.uy + qz * c.uz)) / (kiaw * a.cs + 1e-10);
                         const double e2 = eta * eta;
                         const double P = iaw2 * eta / ((e2 - 1.0) * (e2 - 1.0) + iaw2 * e2);
                         acc += pref * P * Ij;
@@ -1137,10 +1176,10 @@ __global__ void __launch_bounds__(256) k_gain_field(const GainArgs a)
                 raw = acc;
             }
             if (valid) {
-                double *gp = a.gain + (long)bi * hsize + h;
+                double *gp = a.gain + oi + h;
                 const double old = *gp;
                 const double nw = old + a.relax * (raw - old);
-                *gp = nw;
+                if (nw != old) *gp = nw;
                 sum_change += fabs(nw - old);
                 sum_abs += fabs(nw);
             }
@@ -1152,7 +1191,7 @@ __global__ void __launch_bounds__(256) k_gain_field(const GainArgs a)
             sum_change += __shfl_xor(sum_change, off, kWave);
             sum_abs += __shfl_xor(sum_abs, off, kWave);
         }
-        if ((threadIdx.x & (kWave - 1)) == 0) {
+        if (lane == 0) {
             atomicAdd(&a.change[0], sum_change);
             atomicAdd(&a.change[1], sum_abs);
         }
@@ -1175,11 +1214,18 @@ template <int DEPOSIT, int WL, int RL, int PRE, bool FLIP, bool TWOBOX, bool IDX
 static void launch_k(const TraceArgs &a, dim3 grid, hipStream_t stream)
 {
     if constexpr (DEPOSIT == 3 && TWOBOX && RL == 0 && PRE == 0) {  // CBET hooks: default configuration only
-      if (a.gain || a.quantity != 0 || a.beam_gain) {
+      if (a.quantity != 0) {  // the fused four-component field pass
         if (a.absorption == 1)
-            hipLaunchKernelGGL((k_trace<DEPOSIT, WL, RL, PRE, FLIP, TWOBOX, IDX64, true, true>), grid, dim3(kWave), 0, stream, a);
+            hipLaunchKernelGGL((k_trace<DEPOSIT, WL, RL, PRE, FLIP, TWOBOX, IDX64, true, 4>), grid, dim3(kWave), 0, stream, a);
         else
-            hipLaunchKernelGGL((k_trace<DEPOSIT, WL, RL, PRE, FLIP, TWOBOX, IDX64, false, true>), grid, dim3(kWave), 0, stream, a);
+            hipLaunchKernelGGL((k_trace<DEPOSIT, WL, RL, PRE, FLIP, TWOBOX, IDX64, false, 4>), grid, dim3(kWave), 0, stream, a);
+        return;
+      }
+      if (a.gain || a.beam_gain) {
+        if (a.absorption == 1)
+            hipLaunchKernelGGL((k_trace<DEPOSIT, WL, RL, PRE, FLIP, TWOBOX, IDX64, true, 1>), grid, dim3(kWave), 0, stream, a);
+        else
+            hipLaunchKernelGGL((k_trace<DEPOSIT, WL, RL, PRE, FLIP, TWOBOX, IDX64, false, 1>), grid, dim3(kWave), 0, stream, a);
         return;
       }
     }
@@ -1223,20 +1269,11 @@ static void dispatch_trace(const TraceArgs &a, int variant, int wl, int rl, int 
     }
 }
 
-hipError_t launch_field_normalize(const GainArgs &a, hipStream_t stream)
-{
-    const long total = (long)(a.nx + 2) * (a.ny + 2) * (a.nz + 2) * a.nbeams;
-    long blocks = (total + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(k_field_normalize, dim3((unsigned)blocks), dim3(256), 0, stream, a);
-    return hipGetLastError();
-}
-
 hipError_t launch_gain_field(const GainArgs &a, hipStream_t stream)
 {
-    const long hsize = (long)(a.nx + 2) * (a.ny + 2) * (a.nz + 2);
-    long blocks = (hsize + 255) / 256;
-    if (blocks > 256 * 32) blocks = 256 * 32;
+    const long bricks = (long)((a.nx + 3) / 2) * ((a.ny + 5) / 4) * ((a.nz + 9) / 8);  // 2 x 4 x 8 cells of the haloed grid each
+    long blocks = (bricks + 3) / 4;                                                    // four wavefronts per workgroup
+    if (blocks > 256 * 64) blocks = 256 * 64;
     hipLaunchKernelGGL(k_gain_field, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }

@@ -100,14 +100,19 @@ class RayTracer:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         api.tabulate_plasma(self.ctx, self.params, self.d_te, self.d_r, self.d_ne, stream)
 
-    def launch_cbet(self, out, gain_params, quantity=0, gain=None, beam_gain=None, shard_index=0,
+    def launch_cbet(self, out, gain_params, fields=False, gain=None, beam_gain=None, shard_index=0,
                     shard_count=1, ne3d=None, kappa3d=None):
         """One trace with the CBET hooks on torch's current stream (node tables must be filled:
-        tabulate(), or pass ne3d / kappa3d).  out: (n+2)^3 grid or nbeams of them."""
-        per_beam = out.dim() == 4
-        want = ((self.params.nbeams,) + self.grid_shape) if per_beam else self.grid_shape
+        tabulate(), or pass ne3d / kappa3d).  fields=False: deposit the absorbed energy into `out`
+        ((n+2)^3 grid or nbeams of them); fields=True: the fused field pass, `out` = new_fields()."""
+        if fields:
+            want = (4, self.params.nbeams) + self.grid_shape
+            per_beam = True
+        else:
+            per_beam = out.dim() == 4
+            want = ((self.params.nbeams,) + self.grid_shape) if per_beam else self.grid_shape
         if out.dtype != torch.float64 or not out.is_contiguous() or tuple(out.shape) != want:
-            raise ValueError("out must be a contiguous float64 tensor of shape %s (or nbeams x that)" % (self.grid_shape,))
+            raise ValueError("out must be a contiguous float64 tensor of shape %s" % (want,))
         if gain is not None and (gain.dtype != torch.float64 or not gain.is_contiguous() or
                                  tuple(gain.shape) != (self.params.nbeams,) + self.grid_shape):
             raise ValueError("gain must be a contiguous float64 tensor of shape nbeams x %s" % (self.grid_shape,))
@@ -115,13 +120,13 @@ class RayTracer:
                              shard_index=shard_index, shard_count=shard_count)
         d = self.derived
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        api.trace_cbet(0, d.nindices, ne3d, kappa3d, gain, quantity, out, beam_gain, self.d_bbeam_norm,
-                       self.d_beam_norm, self.d_pow_r, self.d_phase_r, d.xconst, d.yconst, d.zconst, p,
-                       gain_params, self.ctx, stream)
+        api.trace_cbet(0, d.nindices, ne3d, kappa3d, gain, api.DEPOSIT_FIELDS if fields else api.DEPOSIT_ENERGY, out,
+                       beam_gain, self.d_bbeam_norm, self.d_beam_norm, self.d_pow_r, self.d_phase_r, d.xconst,
+                       d.yconst, d.zconst, p, gain_params, self.ctx, stream)
         return out
 
     def new_fields(self):
-        """Zeroed [4][nbeams][(n+2)^3] field array (energy x length, energy x displacement x/y/z)."""
+        """Zeroed [4][nbeams][(n+2)^3] field array (energy x path length, energy x displacement x/y/z)."""
         return torch.zeros((4, self.params.nbeams) + self.grid_shape, dtype=torch.float64, device=self.device)
 
     def gain_field(self, fields, gain, gain_params, change=None, ne3d=None):
@@ -187,9 +192,8 @@ class _DeviceCbetEngine:
 
     def field_passes(self, use_gain, shard_index, shard_count):
         self.fields.zero_()
-        for q in (1, 2, 3, 4):
-            self.tr.launch_cbet(self.fields[q - 1], self.gp, quantity=q, gain=self.gain if use_gain else None,
-                                shard_index=shard_index, shard_count=shard_count)
+        self.tr.launch_cbet(self.fields, self.gp, fields=True, gain=self.gain if use_gain else None,
+                            shard_index=shard_index, shard_count=shard_count)
         return self.fields
 
     def update_gain(self, fields):
@@ -199,7 +203,7 @@ class _DeviceCbetEngine:
 
     def deposit(self, shard_index, shard_count):
         self.beam_gain.zero_()
-        self.tr.launch_cbet(self.edep, self.gp, quantity=0, gain=self.gain, beam_gain=self.beam_gain,
+        self.tr.launch_cbet(self.edep, self.gp, gain=self.gain, beam_gain=self.beam_gain,
                             shard_index=shard_index, shard_count=shard_count)
         return self.beam_gain
 
@@ -207,7 +211,7 @@ class _DeviceCbetEngine:
 def cbet_fixed_point(engine, gain_params, rank=0, world_size=1, group=None):
     """The CBET fixed-point iteration over `world_size` ranks (parity unpinned).
 
-    Every pass: each rank deposits the four field quantities of ITS share of the ray bundles (the plain
+    Every pass: each rank deposits the four field components of ITS share of the ray bundles (the plain
     pass's interleaved sharding), the fields are summed over ranks with one all-reduce, and every rank
     updates the full gain coefficient from them (redundantly -- it needs all of it for its own rays).
     Stops when sum |dK| / sum |K| < tolerance, then runs the deposition pass and all-reduces the

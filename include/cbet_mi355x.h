@@ -300,18 +300,25 @@ int cbet_gain_constants(const cbet_params *p, const cbet_gain_params *g, double 
  * cbet_trace_nodes with the CBET hooks.  gain: device [nbeams][(nx+2)(ny+2)(nz+2)] gain coefficient
  * per beam on the deposit grid (1/cm), or NULL; every ray-step gathers it from its eight deposit
  * nodes with the deposit weights and multiplies the ray's energy by exp(K |v| dt) before absorption.
- * quantity: what a step deposits into `out` -- 0 the absorbed energy (the reference's edep), 1 the
- * step-averaged ray energy x path length, 2/3/4 that energy x displacement along x/y/z.  beam_gain:
- * device [nbeams], ADDED into: energy each beam gained (may be NULL).  Default kernel knobs only.
+ * quantity says what a step deposits into `out`:
+ *   CBET_DEPOSIT_ENERGY  the absorbed energy (the reference's edep; `out` as for cbet_trace_nodes);
+ *   CBET_DEPOSIT_FIELDS  the four per-beam fields the gain needs, in ONE trace: out is
+ *       [4][nbeams][(n+2)^3] -- component 0 the step-averaged ray energy x path length, spread over the
+ *       eight deposit nodes with the deposit weights; components 1..3 that energy x the step's
+ *       displacement along x/y/z, at the ray's own (nearest) node.
+ * beam_gain: device [nbeams], ADDED into: energy each beam gained (may be NULL).  Default kernel knobs only.
  */
+#define CBET_DEPOSIT_ENERGY 0
+#define CBET_DEPOSIT_FIELDS 1
 int cbet_trace_cbet(int b, unsigned nindices, const double *ne3d, const double *kappa3d,
                     const double *gain, int quantity, double *out, double *beam_gain,
                     const double *bbeam_norm, const double *beam_norm, const double *pow_r,
                     const double *phase_r, double xconst, double yconst, double zconst,
                     const cbet_params *p, const cbet_gain_params *g, cbet_context *ctx, void *stream);
 /*
- * fields: device [4][nbeams][(n+2)^3] = what quantity 1..4 passes deposited with per_beam_grids;
- * normalised IN PLACE to (intensity, k_x, k_y, k_z).  gain: device [nbeams][(n+2)^3], updated to
+ * fields: device [4][nbeams][(n+2)^3] = what a CBET_DEPOSIT_FIELDS pass deposited;
+ * normalised IN PLACE to (intensity, k_x, k_y, k_z) wherever the beam is present (energy > 0; entries
+ * of absent beams are left as deposited).  gain: device [nbeams][(n+2)^3], updated to
  * gain + relax (K - gain).  change: device double[2], ADDED into: {sum |new - old|, sum |new|}
  * (may be NULL).  ne3d NULL = the context's node table.  Needs nbeams <= CBET_MAX_CBET_BEAMS.
  */
@@ -320,7 +327,7 @@ int cbet_gain_field(double *fields, const double *ne3d, double *gain, double *ch
 /* Bytes of device workspace cbet_cbet_solve needs: 5 nbeams (n+2)^3 doubles + a few scalars. */
 size_t cbet_cbet_workspace_bytes(const cbet_params *p);
 /*
- * The whole iteration on the current device: tabulate the plasma; repeat { four field passes with the
+ * The whole iteration on the current device: tabulate the plasma; repeat { field pass with the
  * current gain -> normalise -> new gain } until converged; then one deposition pass with the
  * converged gain ADDED into edep (device, (n+2)^3).  Profiles and tables are device pointers as for
  * cbet_launch_ray_XYZ.  workspace: device memory of cbet_cbet_workspace_bytes() or NULL (allocated

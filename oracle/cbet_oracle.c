@@ -450,10 +450,12 @@ static int trace_one(const ray_ctx *c, int beam, int pre_raynum)
         }
 
 
-        if (c->quantity == 1) inc = u_eff * ds;             /* energy x path length */
-        else if (c->quantity == 2) inc = u_eff * (vx * dt); /* ... x displacement components */
-        else if (c->quantity == 3) inc = u_eff * (vy * dt);
-        else if (c->quantity == 4) inc = u_eff * (vz * dt);
+        if (c->quantity == 1) inc = u_eff * ds;             /* energy x path length, the eight deposit weights */
+        else if (c->quantity >= 2) {                        /* energy x displacement, at the ray's own node only */
+            inc = u_eff * ((c->quantity == 2 ? vx : (c->quantity == 3 ? vy : vz)) * dt);
+            a1 = 1.0;
+            a2 = a3 = a4 = a5 = a6 = a7 = a8 = 0.0;
+        }
 
         /* :341-348 with :5-7's index */
         {

@@ -143,9 +143,9 @@ void cbet_oracle_gain_constants(const cbet_oracle_config *cfg, const cbet_oracle
                                 double *constant1, double *cs, double *gain_const);
 /* Node-table ray loop of cbet_oracle_trace_tables with the CBET hooks: every step multiplies the ray
  * energy by exp(K |v| dt), K = gain[beam][(n+2)^3] gathered from the step's eight deposit nodes with the
- * deposit weights (gain may be NULL), and deposits `quantity` (0 absorbed energy, 1 arriving ray energy x
- * path length, 2..4 arriving ray energy x displacement x/y/z) into out (one (n+2)^3 grid, or nbeams of
- * them when per_beam).  beam_gain[nbeams] (may be NULL) receives the energy each beam gained. */
+ * deposit weights (gain may be NULL), and deposits `quantity` into out (one (n+2)^3 grid, or nbeams of
+ * them when per_beam): 0 the absorbed energy; 1 the step-averaged ray energy x path length (eight deposit
+ * weights); 2..4 that energy x the step's displacement along x/y/z, at the ray's own node only.  beam_gain[nbeams] (may be NULL) receives the energy each beam gained. */
 long long cbet_oracle_trace_cbet(const cbet_oracle_config *cfg, const cbet_oracle_gain_config *g,
                                  const double *beam_norm, const double *ne3d, const double *kap3d,
                                  const double *gain, int quantity, int per_beam, double *out,

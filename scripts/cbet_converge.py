@@ -22,13 +22,12 @@ for relax in relaxes:
     hist = []
     for it in range(passes):
         fields.zero_()
-        for q in (1, 2, 3, 4):
-            tr.launch_cbet(fields[q - 1], gp, quantity=q, gain=gain if it else None)
+        tr.launch_cbet(fields, gp, fields=True, gain=gain if it else None)
         change.zero_()
         tr.gain_field(fields, gain, gp, change)
         ch = change.cpu().numpy()
         bg.zero_(); e.zero_()
-        tr.launch_cbet(e, gp, quantity=0, gain=gain, beam_gain=bg)
+        tr.launch_cbet(e, gp, gain=gain, beam_gain=bg)
         b = bg.cpu().numpy()
         hist.append((ch[0] / ch[1], abs(b.sum()) / np.abs(b).sum(), float(gain.abs().max())))
     print("relax %.2f" % relax)

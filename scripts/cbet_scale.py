@@ -27,16 +27,14 @@ steps_ref = tr.counters(reset=True).ray_steps // 3
 print("reference pass: %.2f ms (tabulate + trace), %d ray-steps" % (t_ref, steps_ref), flush=True)
 fields, gain = tr.new_fields(), tr.new_grid(per_beam=True)
 tr.tabulate()
-for q in (1, 2, 3, 4):
-    print("field pass q=%d, no gain: %.2f ms" % (q, timed(lambda: tr.launch_cbet(fields[q - 1], gp, quantity=q))), flush=True)
+print("field pass (4 components, one trace), no gain: %.2f ms" % timed(lambda: tr.launch_cbet(fields, gp, fields=True)), flush=True)
 change = torch.zeros(2, dtype=torch.float64, device="cuda")
 t = timed(lambda: tr.gain_field(fields, gain, gp, change))
 print("normalise + gain kernels: %.2f ms; K max %.3g 1/cm" % (t, float(gain.abs().max())), flush=True)
 fields.zero_()
-for q in (1, 2, 3, 4):
-    print("field pass q=%d, with gain: %.2f ms" % (q, timed(lambda: tr.launch_cbet(fields[q - 1], gp, quantity=q, gain=gain))), flush=True)
+print("field pass, with gain: %.2f ms" % timed(lambda: tr.launch_cbet(fields, gp, fields=True, gain=gain)), flush=True)
 e.zero_()
-print("deposition pass with gain: %.2f ms" % timed(lambda: tr.launch_cbet(e, gp, quantity=0, gain=gain)), flush=True)
+print("deposition pass with gain: %.2f ms" % timed(lambda: tr.launch_cbet(e, gp, gain=gain)), flush=True)
 del fields, gain
 torch.cuda.empty_cache()
 e.zero_()

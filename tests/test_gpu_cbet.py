@@ -61,31 +61,41 @@ def test_hooks_off_is_the_reference_path(api, oracle, setup, torch_cuda):
     c_ref = tr.counters(reset=True)
     e = tr.new_grid()
     bg = torch_cuda.zeros(len(BEAMS), dtype=torch_cuda.float64, device="cuda")
-    tr.launch_cbet(e, setup["gp"], quantity=0, gain=None, beam_gain=bg)
+    tr.launch_cbet(e, setup["gp"], gain=None, beam_gain=bg)
     c = tr.counters(reset=True)
     assert c.ray_steps == c_ref.ray_steps
     assert parity_err(e.cpu().numpy(), ref.cpu().numpy()) < TOL
     assert float(bg.abs().sum()) == 0.0
     # a gain field of zeros changes nothing either (x = 0 -> phi = 1 exactly)
     e2 = tr.new_grid()
-    tr.launch_cbet(e2, setup["gp"], quantity=0, gain=tr.new_grid(per_beam=True), beam_gain=bg)
+    tr.launch_cbet(e2, setup["gp"], gain=tr.new_grid(per_beam=True), beam_gain=bg)
     assert tr.counters(reset=True).ray_steps == c_ref.ray_steps
     assert parity_err(e2.cpu().numpy(), ref.cpu().numpy()) < TOL
 
 
-@pytest.mark.parametrize("quantity", [1, 2, 3, 4])
-def test_field_passes_match_oracle(api, setup, torch_cuda, quantity):
+def test_field_pass_matches_oracle(api, setup, torch_cuda):
+    """One fused trace deposits all four per-beam fields; the oracle deposits them one by one."""
     tr = setup["tr"]
-    f = tr.new_grid(per_beam=True)
-    tr.launch_cbet(f, setup["gp"], quantity=quantity)
+    f = tr.new_fields()
+    tr.counters(reset=True)
+    tr.launch_cbet(f, setup["gp"], fields=True)
+    c = tr.counters(reset=True)
+    ref = tr.new_grid()
+    tr.launch(ref)
+    assert c.ray_steps == tr.counters(reset=True).ray_steps     # one trace, not four
     f = f.cpu().numpy()
-    want = setup["ofields"][quantity - 1]
-    for b in range(len(BEAMS)):
-        assert parity_err(f[b], want[b]) < TOL
-    if quantity == 1:  # the energy x length field, divided by the step length, is the beam's intensity
-        d = tr.derived
-        peak = f.max() / (2.99792458e10 * d.dt)
-        assert 0.3e14 < peak < 4e14
+    for q in range(4):
+        for b in range(len(BEAMS)):
+            assert parity_err(f[q, b], setup["ofields"][q, b]) < TOL, (q, b)
+    d = tr.derived                     # energy x length / step length = the beam's intensity, W/cm^2
+    peak = f[0].max() / (2.99792458e10 * d.dt)
+    assert 0.3e14 < peak < 4e14
+    # the displacement components sit on own nodes only: a subset of where energy was deposited
+    assert np.all((f[1:] != 0).any(axis=0) <= (f[0] != 0))
+    # the same fields with a gain field of zeros (x = 0 -> phi = 1 exactly)
+    f0 = tr.new_fields()
+    tr.launch_cbet(f0, setup["gp"], fields=True, gain=tr.new_grid(per_beam=True))
+    assert parity_err(f0.cpu().numpy().reshape(-1), f.reshape(-1)) < TOL
 
 
 def test_gain_field_matches_oracle_and_is_antisymmetric(api, oracle, setup, torch_cuda):
@@ -103,12 +113,14 @@ def test_gain_field_matches_oracle_and_is_antisymmetric(api, oracle, setup, torc
     assert abs(ch[1] / np.abs(want).sum() - 1.0) < 1e-9
     # the normalised fields: intensity and wave vectors; what beams exchange in a cell sums to zero
     nf = fields.cpu().numpy()
-    exch = (nf[0] * K).sum(axis=0)
-    assert np.abs(exch).max() <= 1e-12 * np.abs(nf[0] * K).sum(axis=0).max()
+    inten = np.where(nf[0] > 0, nf[0], 0.0)
+    exch = (inten * K).sum(axis=0)
+    assert np.abs(exch).max() <= 1e-12 * np.abs(inten * K).sum(axis=0).max()
     kmag = np.sqrt(nf[1] ** 2 + nf[2] ** 2 + nf[3] ** 2)
-    present = nf[0] > 0
+    present = setup["ofields"][0] > 0                 # where the beam deposited energy the entry is normalised
     d = tr.derived
-    assert np.all(kmag[present] <= d.omega / 2.99792458e10 * (1 + 1e-12)) and np.all(kmag[~present] == 0)
+    assert np.all(kmag[present] <= d.omega / 2.99792458e10 * (1 + 1e-12))
+    assert np.array_equal(nf[:, ~present], setup["ofields"][:, ~present])   # absent entries are left as deposited
     # under-relaxation: a second call with relax = 0.25 moves a quarter of the way towards the same K
     gain2 = torch_cuda.zeros_like(gain)
     fields2 = torch_cuda.from_numpy(setup["ofields"].copy()).cuda()
@@ -122,7 +134,7 @@ def test_gain_pass_matches_oracle(api, oracle, setup, torch_cuda):
     e = tr.new_grid()
     bg = torch_cuda.zeros(len(BEAMS), dtype=torch_cuda.float64, device="cuda")
     tr.counters(reset=True)
-    tr.launch_cbet(e, gp, quantity=0, gain=gain, beam_gain=bg)
+    tr.launch_cbet(e, gp, gain=gain, beam_gain=bg)
     c = tr.counters(reset=True)
     oe, osteps, obg = oracle.trace_cbet(setup["cfg"], setup["og"], setup["bn"], setup["ne3d"], setup["kap"],
                                         gain=setup["ogain"], nthreads=NCPU)
@@ -174,15 +186,18 @@ def test_cbet_argument_errors(api, setup, torch_cuda):
     with pytest.raises(api.CbetError) as ei:
         tr.launch_cbet(e, api.default_gain_params(max_exponent=2.0))
     assert ei.value.code == api.EINVAL
-    with pytest.raises(api.CbetError) as ei:
-        tr.launch_cbet(e, setup["gp"], quantity=5)
+    d = tr.derived
+    stream = torch_cuda.cuda.current_stream().cuda_stream
+    with pytest.raises(api.CbetError) as ei:   # quantity is CBET_DEPOSIT_ENERGY or CBET_DEPOSIT_FIELDS
+        api.trace_cbet(0, d.nindices, None, None, None, 5, e, None, tr.d_bbeam_norm, tr.d_beam_norm, tr.d_pow_r,
+                       tr.d_phase_r, d.xconst, d.yconst, d.zconst, tr.params.copy(beam_lo=0, beam_hi=len(BEAMS)),
+                       setup["gp"], tr.ctx, stream)
     assert ei.value.code == api.EINVAL
     p = tr.params.copy(kernel_variant=1, beam_lo=0, beam_hi=len(BEAMS))
-    d = tr.derived
     with pytest.raises(api.CbetError) as ei:   # hooks exist for the default kernel only
-        api.trace_cbet(0, d.nindices, None, None, None, 1, e, None, tr.d_bbeam_norm, tr.d_beam_norm, tr.d_pow_r,
-                       tr.d_phase_r, d.xconst, d.yconst, d.zconst, p, setup["gp"], tr.ctx,
-                       torch_cuda.cuda.current_stream().cuda_stream)
+        api.trace_cbet(0, d.nindices, None, None, None, api.DEPOSIT_FIELDS, tr.new_fields(), None, tr.d_bbeam_norm,
+                       tr.d_beam_norm, tr.d_pow_r, tr.d_phase_r, d.xconst, d.yconst, d.zconst, p, setup["gp"], tr.ctx,
+                       stream)
     assert ei.value.code == api.EINVAL
     with pytest.raises(api.CbetError) as ei:
         api.cbet_solve(tr.d_te, tr.d_r, tr.d_ne, e, tr.d_bbeam_norm, tr.d_beam_norm, tr.d_pow_r, tr.d_phase_r,
