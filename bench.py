@@ -64,7 +64,7 @@ def cbet_leg(api, tr, edep, n):
     dt = time.perf_counter() - t0
     bg = np.array(rep.beam_gain[:tr.params.nbeams])
     absorbed = float(edep.sum().item())
-    return {"parity": "unpinned (no reference CBET code; model of DESIGN.md section 10)",
+    return {"parity": "unpinned (no reference CBET code; model of DESIGN.md section 9)",
             "workload": "omega60_%dcube_s83177_absorption + CBET fixed-point iteration" % n,
             "passes": rep.passes, "converged": bool(rep.converged), "gain_change": rep.change,
             "energy_imbalance": rep.imbalance, "seconds": dt,

@@ -168,7 +168,7 @@ def lib():
     L.cbet_gain_constants.argtypes = [C.POINTER(Params), C.POINTER(GainParams), dp, dp, dp]
     L.cbet_trace_cbet.argtypes = [C.c_int, C.c_uint, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp,
                                   C.c_double, C.c_double, C.c_double, C.POINTER(Params), C.POINTER(GainParams), vp, vp]
-    L.cbet_gain_field.argtypes = [vp, vp, vp, vp, C.POINTER(Params), C.POINTER(GainParams), vp, vp]
+    L.cbet_gain_field.argtypes = [vp, vp, vp, vp, vp, C.POINTER(Params), C.POINTER(GainParams), vp, vp]
     L.cbet_cbet_workspace_bytes.argtypes = [C.POINTER(Params)]
     L.cbet_cbet_workspace_bytes.restype = C.c_size_t
     L.cbet_cbet_solve.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(Params), C.POINTER(GainParams), vp, vp, vp,
@@ -392,9 +392,9 @@ def trace_cbet(b, nindices, ne3d, kappa3d, gain, quantity, out, beam_gain, bbeam
         C.byref(params), C.byref(gain_params), ctx.handle, _addr(stream)))
 
 
-def gain_field(fields, ne3d, gain, change, params, gain_params, ctx, stream=None):
-    _check(lib().cbet_gain_field(_addr(fields), _addr(ne3d), _addr(gain), _addr(change), C.byref(params),
-                                 C.byref(gain_params), ctx.handle, _addr(stream)))
+def gain_field(fields, ne3d, gain, scratch, change, params, gain_params, ctx, stream=None):
+    _check(lib().cbet_gain_field(_addr(fields), _addr(ne3d), _addr(gain), _addr(scratch), _addr(change),
+                                 C.byref(params), C.byref(gain_params), ctx.handle, _addr(stream)))
 
 
 def cbet_workspace_bytes(params):

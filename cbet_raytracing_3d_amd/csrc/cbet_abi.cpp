@@ -549,8 +549,8 @@ static int trace_impl(int b, unsigned nindices, const double *ne3d, const double
     if (two && (rl != 0 || pre != 0 || wl != 3 || p->lds_corner_flip == 0))
         return fail(CBET_EINVAL, "lds_two_boxes needs lds_window_log2=3, one copy, no pre-reduction, corner flip on");
     const bool cbet_hooks = hooks.gain || hooks.quantity != 0 || hooks.beam_gain;
-    if (cbet_hooks && !(variant == CBET_KERNEL_LDS_WINDOW && two))
-        return fail(CBET_EINVAL, "the CBET hooks exist for the default kernel configuration only");
+    if (cbet_hooks && !(variant == CBET_KERNEL_LDS_WINDOW && wl == 3 && rl == 0 && pre == 0 && p->lds_corner_flip != 0))
+        return fail(CBET_EINVAL, "the CBET hooks exist for the default kernel configuration (and lds_two_boxes = 0) only");
 
     const cbet_derived &d = ctx->d;
     TraceArgs a{};
@@ -722,7 +722,7 @@ int cbet_trace_cbet(int b, unsigned nindices, const double *ne3d, const double *
                       p, ctx, stream, h);
 }
 
-int cbet_gain_field(double *fields, const double *ne3d, double *gain, double *change,
+int cbet_gain_field(double *fields, const double *ne3d, double *gain, double *scratch, double *change,
                     const cbet_params *p, const cbet_gain_params *g, cbet_context *ctx, void *stream)
 {
     if (!ctx) return fail(CBET_EINVAL, "NULL context");
@@ -741,7 +741,7 @@ int cbet_gain_field(double *fields, const double *ne3d, double *gain, double *ch
     a.cs = cs; a.gain_const = gc; a.iaw = g->iaw;
     a.mach_r0 = g->mach_r0; a.mach_0 = g->mach_0; a.mach_r1 = g->mach_r1; a.mach_1 = g->mach_1;
     a.relax = g->relax;
-    a.fields = fields; a.ne3d = ne3d ? ne3d : ctx->ne3d; a.gain = gain; a.change = change;
+    a.fields = fields; a.ne3d = ne3d ? ne3d : ctx->ne3d; a.gain = gain; a.scratch = scratch; a.change = change;
     DeviceGuard guard;
     CBET_HIP(hipSetDevice(ctx->gpu));
     CBET_HIP(launch_gain_field(a, (hipStream_t)stream));
@@ -752,7 +752,7 @@ size_t cbet_cbet_workspace_bytes(const cbet_params *p)
 {
     if (!p || validate(p) != CBET_OK) return 0;
     const size_t hsize = (size_t)(p->nx + 2) * (p->ny + 2) * (p->nz + 2);
-    return (5 * (size_t)p->nbeams * hsize + 2 + CBET_MAX_CBET_BEAMS) * sizeof(double);
+    return (6 * (size_t)p->nbeams * hsize + 2 + CBET_MAX_CBET_BEAMS) * sizeof(double);
 }
 
 int cbet_cbet_solve(double *te_data_g, double *r_data_g, double *ne_data_g, double *edep,
@@ -783,7 +783,8 @@ int cbet_cbet_solve(double *te_data_g, double *r_data_g, double *ne_data_g, doub
         if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? CBET_ENOMEM : CBET_EHIP, "hipMalloc(cbet workspace, %zu bytes): %s", bytes, hipGetErrorString(e));
         own = true;
     }
-    double *fields = ws, *gain = ws + 4 * nb * hsize, *change = gain + nb * hsize, *beam_gain = change + 2;
+    double *fields = ws, *gain = ws + 4 * nb * hsize, *scratch = gain + nb * hsize, *change = scratch + nb * hsize,
+           *beam_gain = change + 2;
     int rc = CBET_OK;
     cbet_counters c0{}, c1{};
     cbet_cbet_report rep{};
@@ -805,7 +806,7 @@ int cbet_cbet_solve(double *te_data_g, double *r_data_g, double *ne_data_g, doub
                     return r;
             }
             CBET_HIP(hipMemsetAsync(change, 0, 2 * sizeof(double), s));
-            if (int r = cbet_gain_field(fields, nullptr, gain, change, p, g, ctx, stream)) return r;
+            if (int r = cbet_gain_field(fields, nullptr, gain, scratch, change, p, g, ctx, stream)) return r;
             double hc[2];
             CBET_HIP(hipMemcpyAsync(hc, change, sizeof hc, hipMemcpyDeviceToHost, s));
             CBET_HIP(hipStreamSynchronize(s));

@@ -70,7 +70,7 @@ struct TraceArgs {
     long grid_stride;                       // 0: one grid for all beams; else doubles between per-beam grids
     unsigned long long *counters;
     unsigned long long *timeline;           // diagnostic builds only: 3 words per workgroup, else NULL
-    // CBET extension (no reference counterpart; DESIGN.md section 10).  All zero / NULL = the reference path.
+    // CBET extension (no reference counterpart; DESIGN.md section 9).  All zero / NULL = the reference path.
     const double *gain;                     // [nbeams][(n+2)^3] gain coefficient on the deposit grid, 1/cm
     long hsize;                             // (nx+2)(ny+2)(nz+2)
     int quantity;                           // 0: deposit the absorbed energy; 1: the four field components (fused field pass)
@@ -90,6 +90,7 @@ struct GainArgs {
     double *fields;                         // [4][nbeams][hsize]: (E, Dx, Dy, Dz) in; (I, kx, ky, kz) out where the beam is present
     const double *ne3d;                     // [nx*ny*nz]
     double *gain;                           // [nbeams][hsize]
+    double *scratch;                        // [nbeams][hsize] work array of the symmetric kernel, or NULL (ordered kernel)
     double *change;                         // device {sum |new-old|, sum |new|} accumulators, or NULL
 };
 

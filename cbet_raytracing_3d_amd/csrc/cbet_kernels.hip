@@ -369,11 +369,13 @@ struct MovingWindow {
     static constexpr int NDOUBLES = R * CS;
     double *val;                          // NDOUBLES accumulators
     int ox, oy, oz;
-    // NC > 1 (CBET field pass): NC - 1 further tiles of the same geometry, `cstride` doubles apart in
-    // LDS, flushed to grids `gstride` doubles apart in HBM (components 1.. are never deferred)
+    // NC > 1 (CBET field pass): NC - 1 further, unpadded W^3 tiles at val + coff + (q - 1) * DT, q = 1..,
+    // flushed to grids `gstride` doubles apart in HBM (components 1.. are never deferred)
+    static constexpr int DT = W * W * W;
     int limit;                            // doubles addressable from val (all boxes' and components' tiles)
-    int cstride;
+    int coff;
     long gstride;
+    static __device__ __forceinline__ int addr_d(int rx, int ry, int rz) { return (rx * W + ry) * W + rz; }
 
     static __device__ __forceinline__ int addr(int rx, int ry, int rz) { return rx * XS + ry * YS + rz; }
 
@@ -402,9 +404,10 @@ struct MovingWindow {
         for (int e = lane; e < W * W; e += kWave) {
             const int r0 = e >> WL, r1 = e & (W - 1);
             int i, j, k, slot;
-            if (AX == 0) { i = coord; j = absolute(oy, r0); k = absolute(oz, r1); slot = addr(fixed, r0, r1); }
-            else if (AX == 1) { i = absolute(ox, r0); j = coord; k = absolute(oz, r1); slot = addr(r0, fixed, r1); }
-            else { i = absolute(ox, r0); j = absolute(oy, r1); k = coord; slot = addr(r0, r1, fixed); }
+            int slot_d = 0;
+            if (AX == 0) { i = coord; j = absolute(oy, r0); k = absolute(oz, r1); slot = addr(fixed, r0, r1); slot_d = addr_d(fixed, r0, r1); }
+            else if (AX == 1) { i = absolute(ox, r0); j = coord; k = absolute(oz, r1); slot = addr(r0, fixed, r1); slot_d = addr_d(r0, fixed, r1); }
+            else { i = absolute(ox, r0); j = absolute(oy, r1); k = coord; slot = addr(r0, r1, fixed); slot_d = addr_d(r0, r1, fixed); }
             if (!CBET_AUDIT((unsigned)((R - 1) * CS + slot) < (unsigned)NDOUBLES)) continue;
             double v = val[slot];
 #pragma unroll
@@ -413,10 +416,12 @@ struct MovingWindow {
             if (NC > 1) {
 #pragma unroll
                 for (int q = 1; q < NC; ++q) {
-                    const double vq = val[q * cstride + slot];
+                    const double vq = val[coff + (q - 1) * DT + slot_d];
                     if (vq != 0.0) {
+#ifndef CBET_EXPERIMENT_DROP_FLUSH_ATOMICS
                         global_add(&edep[q * gstride + node], vq);
-                        val[q * cstride + slot] = 0.0;
+#endif
+                        val[coff + (q - 1) * DT + slot_d] = 0.0;
                         ++n_at;
                     }
                 }
@@ -567,7 +572,10 @@ __device__ __forceinline__ double phi_det(double x)
 //   CBET = 1: the deposit is the absorbed energy, as in the reference path;
 //   CBET = 4: the field pass -- FOUR grids per beam in one trace: energy x path length with the eight
 //             deposit weights (component 0) and energy x displacement x/y/z at the ray's own node
-//             (components 1..3), each component in its own LDS tile of the moving window.
+//             (components 1..3).  Components 1..3 have an unpadded 8^3 LDS tile each in box A only
+//             (22.2 KB per wave, 7 waves per CU; padded tiles for both boxes left 4 waves per CU and
+//             65 ms without any atomic, against 22 ms for the plain pass); lanes homed in box B add
+//             their three values straight to HBM.
 template <int DEPOSIT, int WL, int RL, int PRE, bool FLIP, bool TWOBOX, bool IDX64, bool ABSORB, int CBET = 0>
 __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
 {
@@ -576,7 +584,8 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
                                          : (DEPOSIT == 2 ? (1 << (3 * WL)) : 1);
     constexpr int NTAG = (DEPOSIT == 2) ? NSLOT : 1;
     constexpr int W = 1 << WL;
-    __shared__ double s_val[NSLOT * NC];
+    constexpr int NLDS = NSLOT + (NC - 1) * MovingWindow<WL, RL>::DT;   // + components 1.. of box A
+    __shared__ double s_val[NLDS];
     __shared__ unsigned s_tag[NTAG];
     const int lane = threadIdx.x;
 #ifdef CBET_EXPERIMENT_EXTRA_LDS  // occupancy-sensitivity experiment builds only (scripts/experiment_occupancy.sh)
@@ -635,13 +644,13 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
     unsigned w_slabs_wide = 0;   // slabs retired << 16 | wave-steps "too wide" (two boxes: box B live)
 
     LdsWindow<WL> tagged{s_val, s_tag};
-    MovingWindow<WL, RL, NC> win{s_val, 0, 0, 0, NSLOT * NC, NSLOT, a.comp_stride};
+    MovingWindow<WL, RL, NC> win{s_val, 0, 0, 0, NLDS, NSLOT, a.comp_stride};
     // Second box (TWOBOX): after the turning point a bundle fans out to 6-11 cells (scripts/
     // bundle_spread.py), wider than one 8-cell box.  Lanes that fall out of box A are adopted by
     // box B (sticky per-lane home bit); B is created around the first such lane and flushed when
     // its last lane leaves or dies.
-    MovingWindow<WL, RL, NC> winB{s_val + (TWOBOX ? MovingWindow<WL, RL>::NDOUBLES : 0), 0, 0, 0,
-                                  MovingWindow<WL, RL>::NDOUBLES, NSLOT, a.comp_stride};
+    MovingWindow<WL, RL> winB{s_val + (TWOBOX ? MovingWindow<WL, RL>::NDOUBLES : 0), 0, 0, 0,
+                              MovingWindow<WL, RL>::NDOUBLES, 0, 0};
     bool homeB = false;     // per lane
     bool b_active = false;  // wave-uniform
 
@@ -657,7 +666,7 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
                  __builtin_amdgcn_readlane(s.ck, src) + 1);
         if (TWOBOX) winB.init(lane, 0, 0, 0);
         if (NC > 1)
-            for (int z = NSLOT + lane; z < NSLOT * NC; z += kWave) s_val[z] = 0.0;  // the further components' tiles
+            for (int z = NSLOT + lane; z < NLDS; z += kWave) s_val[z] = 0.0;  // the further components' tiles
         __syncthreads();
     }
 
@@ -979,12 +988,6 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
                 win.add(x1 + y1 + z0, wgt[5]);
                 win.add(x0 + y1 + z1, wgt[6]);
                 win.add(x1 + y1 + z1, wgt[7]);
-                if (CBET == 4) {  // displacement components: the ray's own node only
-                    const int own = (hi & (W - 1)) * MW::XS + (hj & (W - 1)) * MW::YS + (hk & (W - 1)) + copy;
-                    win.add(own + NSLOT, q1);
-                    win.add(own + 2 * NSLOT, q2);
-                    win.add(own + 3 * NSLOT, q3);
-                }
             } else if (alive && !inbox) {
 #ifndef CBET_EXPERIMENT_DROP_MISS_ATOMICS  // timing-only experiment builds; never shipped
                 const int nX0 = __mul24(X0, sXh), nX1 = __mul24(X1, sXh), nY0 = __mul24(Y0, sYh), nY1 = __mul24(Y1, sYh);
@@ -996,16 +999,28 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
                 global_add(&edep[nX1 + nY1 + Z0], wgt[5]);
                 global_add(&edep[nX0 + nY1 + Z1], wgt[6]);
                 global_add(&edep[nX1 + nY1 + Z1], wgt[7]);
-                if (CBET == 4) {
-                    const int own = __mul24(hi, sXh) + __mul24(hj, sYh) + hk;
-                    global_add(&edep[a.comp_stride + own], q1);
-                    global_add(&edep[2 * a.comp_stride + own], q2);
-                    global_add(&edep[3 * a.comp_stride + own], q3);
-                    n_atomics += 3;
-                }
 #endif
                 n_atomics += 8;
                 ++n_evict;  // counted as "ray-steps that missed the window"
+            }
+            if (CBET == 4 && alive) {
+                // Displacement components: the ray's own node only -- box A's tiles, or HBM for a lane of
+                // box B / outside the boxes.  (Merging the four rays of a quad in registers first, which
+                // quarters the same-address LDS adds, changed nothing: 49.9 ms either way.)
+                if (inbox && tile == 0) {
+                    const int own = MW::addr_d(hi & (W - 1), hj & (W - 1), hk & (W - 1)) + NSLOT;
+                    win.add(own, q1);
+                    win.add(own + MW::DT, q2);
+                    win.add(own + 2 * MW::DT, q3);
+                } else {
+                    const int own = __mul24(hi, sXh) + __mul24(hj, sYh) + hk;
+#ifndef CBET_EXPERIMENT_DROP_MISS_ATOMICS
+                    global_add(&edep[a.comp_stride + own], q1);
+                    global_add(&edep[2 * a.comp_stride + own], q2);
+                    global_add(&edep[3 * a.comp_stride + own], q3);
+#endif
+                    n_atomics += 3;
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -1067,7 +1082,7 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
 
 
 // ---------------------------------------------------------------------------------------------
-// CBET extension (no reference counterpart; model and layout in DESIGN.md section 10).
+// CBET extension (no reference counterpart; model and layout in DESIGN.md section 9).
 // Deposit-grid cell (hi,hj,hk) takes its plasma state from node (hi-1,hj-1,hk-1), clamped.
 // ---------------------------------------------------------------------------------------------
 struct CellState {
@@ -1198,6 +1213,170 @@ __global__ void __launch_bounds__(256) k_gain_field(const GainArgs a)
     }
 }
 
+
+// The same update with every unordered beam pair evaluated ONCE (G_ji = -G_ij exactly: eta changes sign,
+// P is odd): the present beams of a brick are taken in tiles of GT, a tile pair (A, B) is GT x GT
+// statically unrolled pair bodies on registers, A's sums stay in registers across its B tiles and B's go
+// to `scratch` (read-modify-write by the owning lane; the lines stay in L1/L2).  Half the pair
+// evaluations of k_gain_field and an eighth of its loads; sums are grouped by tile, so K differs
+// from the ordered kernel's in the last bits only.
+constexpr int GT = 6;
+
+struct BeamAtCell {
+    double I, kx, ky, kz;
+};
+
+// pref * P(eta_ij) for the pair (i, j); zero intensities make the products vanish, no branch needed
+__device__ __forceinline__ double pair_gain(const BeamAtCell &bi, const BeamAtCell &bj, double ux, double uy, double uz,
+                                            double cs, double iaw2, double pref)
+{
+    const double qx = bj.kx - bi.kx, qy = bj.ky - bi.ky, qz = bj.kz - bi.kz;
+    const double kiaw = sqrt(qx * qx + qy * qy + qz * qz);
+    const double eta = (0.0 - (qx * ux + qy * uy + qz * uz)) / (kiaw * cs + 1e-10);
+    const double e2 = eta * eta;
+    const double P = iaw2 * eta / ((e2 - 1.0) * (e2 - 1.0) + iaw2 * e2);
+    return pref * P;
+}
+
+__global__ void __launch_bounds__(256) k_gain_field_sym(const GainArgs a)
+{
+    const int HX = a.nx + 2, HY = a.ny + 2, HZ = a.nz + 2;
+    const long hsize = (long)HX * HY * HZ;
+    const long total = hsize * a.nbeams;
+    const int bx = (HX + 1) / 2, by = (HY + 3) / 4, bz = (HZ + 7) / 8;
+    const long bricks = (long)bx * by * bz;
+    const int lane = threadIdx.x & (kWave - 1);
+    const long wave0 = (long)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    const long nwaves = (long)gridDim.x * (blockDim.x / kWave);
+    const double iaw2 = a.iaw * a.iaw;
+    double sum_change = 0.0, sum_abs = 0.0;
+    for (long brick = wave0; brick < bricks; brick += nwaves) {
+        const int ibz = (int)(brick % bz);
+        const long t = brick / bz;
+        const int iby = (int)(t % by), ibx = (int)(t / by);
+        const int hi = 2 * ibx + (lane >> 5), hj = 4 * iby + ((lane >> 3) & 3), hk = 8 * ibz + (lane & 7);
+        const bool valid = hi < HX && hj < HY && hk < HZ;
+        const long h = valid ? ((long)hi * HY + hj) * HZ + hk : 0;
+        double *fI = a.fields + h, *fx = fI + total, *fy = fx + total, *fz = fy + total;
+        double *raw = a.scratch + h;
+        const CellState c = cell_state(a, h);
+        const double kmag = a.k0 * c.rt;
+        const double ds_node = (kC * c.rt) * a.dt;
+        unsigned long long mask = 0ull;
+        for (int b = 0; b < a.nbeams; ++b) {  // phase 1: as k_gain_field, plus the scratch sums start at zero
+            const long o = (long)b * hsize;
+            const double E = valid ? fI[o] : 0.0;
+            const bool pres = E > 0.0;
+            if (__builtin_amdgcn_ballot_w64(pres) == 0ull) continue;
+            mask |= 1ull << b;
+            if (valid) raw[o] = 0.0;
+            if (pres) {
+                const double ax = fx[o], ay = fy[o], az = fz[o];
+                const double dn = sqrt(ax * ax + ay * ay + az * az);
+                double I = 0.0, kx = 0.0, ky = 0.0, kz = 0.0;
+                if (c.eps > 0.0 && dn > 0.0) {
+                    I = E / ds_node;
+                    kx = kmag * (ax / dn);
+                    ky = kmag * (ay / dn);
+                    kz = kmag * (az / dn);
+                }
+                fI[o] = I; fx[o] = kx; fy[o] = ky; fz[o] = kz;
+            }
+        }
+        const double pref = (valid && c.eps > 0.0) ? a.gain_const * c.frac * (1.0 / a.iaw) / c.rt : 0.0;
+        auto load_tile = [&](unsigned long long &m, int (&id)[GT], BeamAtCell (&bm)[GT]) {
+#pragma unroll
+            for (int s = 0; s < GT; ++s) {
+                id[s] = -1;
+                bm[s].I = 0.0; bm[s].kx = 0.0; bm[s].ky = 0.0; bm[s].kz = 0.0;
+                if (m != 0ull) {
+                    id[s] = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const long o = (long)id[s] * hsize;
+                    const double I = fI[o];
+                    bm[s].I = I > 0.0 ? I : 0.0;          // an absent beam's entry is whatever was deposited: mask it
+                    bm[s].kx = fx[o]; bm[s].ky = fy[o]; bm[s].kz = fz[o];
+                }
+            }
+        };
+        unsigned long long ma = mask;
+        while (ma != 0ull) {
+            int aid[GT];
+            BeamAtCell A[GT];
+            load_tile(ma, aid, A);
+            double KA[GT];
+#pragma unroll
+            for (int s = 0; s < GT; ++s) KA[s] = 0.0;
+#pragma unroll
+            for (int s = 0; s < GT; ++s)
+#pragma unroll
+                for (int u = s + 1; u < GT; ++u) {
+                    const double g = pair_gain(A[s], A[u], c.ux, c.uy, c.uz, a.cs, iaw2, pref);
+                    KA[s] += g * A[u].I;
+                    KA[u] -= g * A[s].I;
+                }
+            unsigned long long mb = ma;
+            while (mb != 0ull) {
+                int bid[GT];
+                BeamAtCell B[GT];
+                load_tile(mb, bid, B);
+                double KB[GT];
+#pragma unroll
+                for (int u = 0; u < GT; ++u) KB[u] = 0.0;
+#pragma unroll
+                for (int s = 0; s < GT; ++s)
+#pragma unroll
+                    for (int u = 0; u < GT; ++u) {
+                        const double g = pair_gain(A[s], B[u], c.ux, c.uy, c.uz, a.cs, iaw2, pref);
+                        KA[s] += g * B[u].I;
+                        KB[u] -= g * A[s].I;
+                    }
+#pragma unroll
+                for (int u = 0; u < GT; ++u)
+                    if (bid[u] >= 0 && valid) raw[(long)bid[u] * hsize] += KB[u];
+            }
+#pragma unroll
+            for (int s = 0; s < GT; ++s)
+                if (aid[s] >= 0 && valid) {
+                    const long o = (long)aid[s] * hsize;
+                    // a beam that is absent from THIS cell has K = 0 (its sums above came from whatever its
+                    // entry held); its intensity was masked to zero, so it gave nothing to the others
+                    const double r = A[s].I > 0.0 ? raw[o] + KA[s] : 0.0;
+                    double *gp = a.gain + o + h;
+                    const double old = *gp;
+                    const double nw = old + a.relax * (r - old);
+                    if (nw != old) *gp = nw;
+                    sum_change += fabs(nw - old);
+                    sum_abs += fabs(nw);
+                }
+        }
+        if (valid) {  // beams absent from the whole brick relax towards zero
+            unsigned long long rest = ~mask & (a.nbeams >= 64 ? ~0ull : ((1ull << a.nbeams) - 1));
+            while (rest != 0ull) {
+                const int b = __ffsll((long long)rest) - 1;
+                rest &= rest - 1;
+                double *gp = a.gain + (long)b * hsize + h;
+                const double old = *gp;
+                const double nw = old + a.relax * (0.0 - old);
+                if (nw != old) *gp = nw;
+                sum_change += fabs(nw - old);
+                sum_abs += fabs(nw);
+            }
+        }
+    }
+    if (a.change) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            sum_change += __shfl_xor(sum_change, off, kWave);
+            sum_abs += __shfl_xor(sum_abs, off, kWave);
+        }
+        if (lane == 0) {
+            atomicAdd(&a.change[0], sum_change);
+            atomicAdd(&a.change[1], sum_abs);
+        }
+    }
+}
+
 }  // namespace
 
 hipError_t launch_tabulate(const TabulateArgs &a, hipStream_t stream)
@@ -1213,7 +1392,7 @@ hipError_t launch_tabulate(const TabulateArgs &a, hipStream_t stream)
 template <int DEPOSIT, int WL, int RL, int PRE, bool FLIP, bool TWOBOX, bool IDX64>
 static void launch_k(const TraceArgs &a, dim3 grid, hipStream_t stream)
 {
-    if constexpr (DEPOSIT == 3 && TWOBOX && RL == 0 && PRE == 0) {  // CBET hooks: default configuration only
+    if constexpr (DEPOSIT == 3 && FLIP && RL == 0 && PRE == 0) {  // CBET hooks: the two-box default and its one-box sibling
       if (a.quantity != 0) {  // the fused four-component field pass
         if (a.absorption == 1)
             hipLaunchKernelGGL((k_trace<DEPOSIT, WL, RL, PRE, FLIP, TWOBOX, IDX64, true, 4>), grid, dim3(kWave), 0, stream, a);
@@ -1274,7 +1453,8 @@ hipError_t launch_gain_field(const GainArgs &a, hipStream_t stream)
     const long bricks = (long)((a.nx + 3) / 2) * ((a.ny + 5) / 4) * ((a.nz + 9) / 8);  // 2 x 4 x 8 cells of the haloed grid each
     long blocks = (bricks + 3) / 4;                                                    // four wavefronts per workgroup
     if (blocks > 256 * 64) blocks = 256 * 64;
-    hipLaunchKernelGGL(k_gain_field, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    if (a.scratch) hipLaunchKernelGGL(k_gain_field_sym, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(k_gain_field, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

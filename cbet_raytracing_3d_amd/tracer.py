@@ -101,7 +101,7 @@ class RayTracer:
         api.tabulate_plasma(self.ctx, self.params, self.d_te, self.d_r, self.d_ne, stream)
 
     def launch_cbet(self, out, gain_params, fields=False, gain=None, beam_gain=None, shard_index=0,
-                    shard_count=1, ne3d=None, kappa3d=None):
+                    shard_count=1, ne3d=None, kappa3d=None, lds_two_boxes=None):
         """One trace with the CBET hooks on torch's current stream (node tables must be filled:
         tabulate(), or pass ne3d / kappa3d).  fields=False: deposit the absorbed energy into `out`
         ((n+2)^3 grid or nbeams of them); fields=True: the fused field pass, `out` = new_fields()."""
@@ -118,6 +118,8 @@ class RayTracer:
             raise ValueError("gain must be a contiguous float64 tensor of shape nbeams x %s" % (self.grid_shape,))
         p = self.params.copy(per_beam_grids=1 if per_beam else 0, beam_lo=0, beam_hi=self.params.nbeams,
                              shard_index=shard_index, shard_count=shard_count)
+        if lds_two_boxes is not None:
+            p.lds_two_boxes = lds_two_boxes
         d = self.derived
         stream = torch.cuda.current_stream(self.device).cuda_stream
         api.trace_cbet(0, d.nindices, ne3d, kappa3d, gain, api.DEPOSIT_FIELDS if fields else api.DEPOSIT_ENERGY, out,
@@ -129,10 +131,11 @@ class RayTracer:
         """Zeroed [4][nbeams][(n+2)^3] field array (energy x path length, energy x displacement x/y/z)."""
         return torch.zeros((4, self.params.nbeams) + self.grid_shape, dtype=torch.float64, device=self.device)
 
-    def gain_field(self, fields, gain, gain_params, change=None, ne3d=None):
-        """Normalise `fields` in place and relax `gain` towards the gain coefficient they imply."""
+    def gain_field(self, fields, gain, gain_params, change=None, ne3d=None, scratch=None):
+        """Normalise `fields` in place and relax `gain` towards the gain coefficient they imply.
+        scratch: a work array shaped like `gain` (each beam pair evaluated once), or None (ordered kernel)."""
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        api.gain_field(fields, ne3d, gain, change, self.params, gain_params, self.ctx, stream)
+        api.gain_field(fields, ne3d, gain, scratch, change, self.params, gain_params, self.ctx, stream)
         return gain
 
     def cbet_solve(self, edep, gain_params, rank=0, world_size=1, group=None, fields=None, gain=None):
@@ -183,6 +186,7 @@ class _DeviceCbetEngine:
         self.tr, self.edep, self.gp = tracer, edep, gain_params
         self.fields = tracer.new_fields() if fields is None else fields
         self.gain = tracer.new_grid(per_beam=True) if gain is None else gain
+        self.scratch = torch.empty_like(self.gain)
         self.change = torch.zeros(2, dtype=torch.float64, device=tracer.device)
         self.beam_gain = torch.zeros(tracer.params.nbeams, dtype=torch.float64, device=tracer.device)
 
@@ -198,7 +202,7 @@ class _DeviceCbetEngine:
 
     def update_gain(self, fields):
         self.change.zero_()
-        self.tr.gain_field(fields, self.gain, self.gp, self.change)
+        self.tr.gain_field(fields, self.gain, self.gp, self.change, scratch=self.scratch)
         return self.change
 
     def deposit(self, shard_index, shard_count):

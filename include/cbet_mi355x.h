@@ -259,7 +259,7 @@ int cbet_edep_average(const double *edep, double *edepavg, int nx, int ny, int n
  * PARITY UNPINNED.  The reference has no cross-beam energy transfer code -- only the unused constants
  * of def.cuh:94-114 (estat, mach, Z, mi, Te, Ti, iaw, kb, constant1, cs, u_flow) -- so this stage has
  * no reference output to match.  It implements the steady-state ion-acoustic gain of the ray-based
- * CBET codes those constants come from, on per-beam FIELDS of the deposit grid (DESIGN.md section 10):
+ * CBET codes those constants come from, on per-beam FIELDS of the deposit grid (DESIGN.md section 9):
  *
  *   dI_i/ds = I_i K_i,   K_i = sum_{j != i} G_ij I_j,   G_ij = -G_ji
  *   G_ij = constant1 (8 pi 1e7 / c) (ne/ncrit) (1/iaw) P(eta_ij) / sqrt(1 - ne/ncrit)
@@ -320,11 +320,14 @@ int cbet_trace_cbet(int b, unsigned nindices, const double *ne3d, const double *
  * normalised IN PLACE to (intensity, k_x, k_y, k_z) wherever the beam is present (energy > 0; entries
  * of absent beams are left as deposited).  gain: device [nbeams][(n+2)^3], updated to
  * gain + relax (K - gain).  change: device double[2], ADDED into: {sum |new - old|, sum |new|}
- * (may be NULL).  ne3d NULL = the context's node table.  Needs nbeams <= CBET_MAX_CBET_BEAMS.
+ * (may be NULL).  scratch: device [nbeams][(n+2)^3] work array (contents ignored and overwritten) --
+ * with it every unordered beam pair is evaluated once; NULL selects the ordered kernel (twice the
+ * pair evaluations, no extra memory; K equal to the last bits).  ne3d NULL = the context's node table.
+ * Needs nbeams <= CBET_MAX_CBET_BEAMS.
  */
-int cbet_gain_field(double *fields, const double *ne3d, double *gain, double *change,
+int cbet_gain_field(double *fields, const double *ne3d, double *gain, double *scratch, double *change,
                     const cbet_params *p, const cbet_gain_params *g, cbet_context *ctx, void *stream);
-/* Bytes of device workspace cbet_cbet_solve needs: 5 nbeams (n+2)^3 doubles + a few scalars. */
+/* Bytes of device workspace cbet_cbet_solve needs: 6 nbeams (n+2)^3 doubles + a few scalars. */
 size_t cbet_cbet_workspace_bytes(const cbet_params *p);
 /*
  * The whole iteration on the current device: tabulate the plasma; repeat { field pass with the

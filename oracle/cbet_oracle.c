@@ -656,7 +656,7 @@ void cbet_oracle_node_tables(const cbet_oracle_config *cfg, const double *r_prof
  * CBET extension -- PARITY UNPINNED.  The reference has no cross-beam energy transfer code, only the
  * unused constants of def.cuh:94-114; nothing below can be checked against it.  The model is the
  * steady-state ion-acoustic gain of the 2-D ray-based CBET codes those constants come from, written
- * for per-beam intensity / direction FIELDS on the grid (see DESIGN.md section 10):
+ * for per-beam intensity / direction FIELDS on the grid (see DESIGN.md section 9):
  *
  *   dI_i/ds = I_i * K_i,     K_i(node) = sum_{j != i} G_ij I_j,    G_ij = -G_ji
  *   G_ij = gain_const * (ne/ncrit) * (1/iaw) * P(eta_ij) / sqrt(eps),   eps = 1 - ne/ncrit

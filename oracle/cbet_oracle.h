@@ -126,7 +126,7 @@ void cbet_oracle_node_tables(const cbet_oracle_config *cfg, const double *r_prof
 /* ---- CBET extension: PARITY UNPINNED -----------------------------------------------------------
  * The reference contains no cross-beam energy transfer code (only the unused constants of
  * def.cuh:94-114), so nothing here can be checked against it.  These functions restate on the CPU the
- * field-based gain model the product implements (DESIGN.md section 10) and serve only as the checker
+ * field-based gain model the product implements (DESIGN.md section 9) and serve only as the checker
  * of that HIP implementation. */
 typedef struct cbet_oracle_gain_config {
     double z_ion;              /* def.cuh:100 */

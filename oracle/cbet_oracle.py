@@ -224,7 +224,7 @@ def node_tables(cfg, r, ne, te):
     return ne3d, kap
 
 
-# ---- CBET extension (parity unpinned; checker of the HIP implementation of DESIGN.md section 10) ----
+# ---- CBET extension (parity unpinned; checker of the HIP implementation of DESIGN.md section 9) ----
 def gain_default(**overrides):
     g = GainConfig()
     lib().cbet_oracle_gain_default(C.byref(g))

@@ -14,6 +14,7 @@ tr = RayTracer(api.default_params(n, nbeams=nb), r, ne, te)
 tr.tabulate()
 fields, gain = tr.new_fields(), tr.new_grid(per_beam=True)
 change = torch.zeros(2, dtype=torch.float64, device="cuda")
+scratch = torch.empty_like(gain)
 bg = torch.zeros(nb, dtype=torch.float64, device="cuda")
 e = tr.new_grid()
 for relax in relaxes:
@@ -24,7 +25,7 @@ for relax in relaxes:
         fields.zero_()
         tr.launch_cbet(fields, gp, fields=True, gain=gain if it else None)
         change.zero_()
-        tr.gain_field(fields, gain, gp, change)
+        tr.gain_field(fields, gain, gp, change, scratch=scratch)
         ch = change.cpu().numpy()
         bg.zero_(); e.zero_()
         tr.launch_cbet(e, gp, gain=gain, beam_gain=bg)

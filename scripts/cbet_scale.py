@@ -29,13 +29,14 @@ fields, gain = tr.new_fields(), tr.new_grid(per_beam=True)
 tr.tabulate()
 print("field pass (4 components, one trace), no gain: %.2f ms" % timed(lambda: tr.launch_cbet(fields, gp, fields=True)), flush=True)
 change = torch.zeros(2, dtype=torch.float64, device="cuda")
-t = timed(lambda: tr.gain_field(fields, gain, gp, change))
+scratch = torch.empty_like(gain)
+t = timed(lambda: tr.gain_field(fields, gain, gp, change, scratch=scratch))
 print("normalise + gain kernels: %.2f ms; K max %.3g 1/cm" % (t, float(gain.abs().max())), flush=True)
 fields.zero_()
 print("field pass, with gain: %.2f ms" % timed(lambda: tr.launch_cbet(fields, gp, fields=True, gain=gain)), flush=True)
 e.zero_()
 print("deposition pass with gain: %.2f ms" % timed(lambda: tr.launch_cbet(e, gp, gain=gain)), flush=True)
-del fields, gain
+del fields, gain, scratch
 torch.cuda.empty_cache()
 e.zero_()
 ws = torch.empty(api.cbet_workspace_bytes(tr.params) // 8, dtype=torch.float64, device="cuda")

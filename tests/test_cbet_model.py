@@ -123,7 +123,7 @@ def test_gain_params_and_constants_host_side(api, oracle, case):
     c1, cs, gc = api.gain_constants(p, g)
     assert (c1, cs, gc) == oracle.gain_constants(case["cfg"], og)
     assert 3.9e7 < cs < 4.1e7                           # def.cuh:113 "approx. 4e7 cm/s in this example"
-    assert api.cbet_workspace_bytes(p) == (5 * len(BEAMS) * (N + 2) ** 3 + 2 + api.MAX_CBET_BEAMS) * 8
+    assert api.cbet_workspace_bytes(p) == (6 * len(BEAMS) * (N + 2) ** 3 + 2 + api.MAX_CBET_BEAMS) * 8
     for bad in (dict(max_exponent=0.0), dict(max_exponent=1.5), dict(relax=0.0), dict(relax=1.01), dict(iaw=0.0),
                 dict(mach_r1=0.01)):
         with pytest.raises(api.CbetError) as ei:

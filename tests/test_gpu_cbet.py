@@ -1,7 +1,7 @@
 """CBET stage on the GPU against the CPU restatement of the same model.
 
 PARITY UNPINNED: the reference has no CBET code (def.cuh:94-114 holds unused constants only), so these
-tests compare the HIP implementation with oracle/'s restatement of the model DESIGN.md section 10
+tests compare the HIP implementation with oracle/'s restatement of the model DESIGN.md section 9
 defines, and check the properties the model promises: hooks off = the reference path, exact pairwise
 antisymmetry of the exchange, energy conservation at the fixed point.
 """
@@ -98,24 +98,30 @@ def test_field_pass_matches_oracle(api, setup, torch_cuda):
     assert parity_err(f0.cpu().numpy().reshape(-1), f.reshape(-1)) < TOL
 
 
-def test_gain_field_matches_oracle_and_is_antisymmetric(api, oracle, setup, torch_cuda):
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_gain_field_matches_oracle_and_is_antisymmetric(api, oracle, setup, torch_cuda, symmetric):
+    """Both gain kernels: the ordered one (the oracle's sum order) and the one that evaluates every
+    unordered pair once into a scratch array (sums grouped by beam tile)."""
     tr, gp = setup["tr"], setup["gp"]
     fields = torch_cuda.from_numpy(setup["ofields"].copy()).cuda()
     gain = tr.new_grid(per_beam=True)
+    scratch = torch_cuda.full_like(gain, float("nan")) if symmetric else None   # contents must not matter
     change = torch_cuda.zeros(2, dtype=torch_cuda.float64, device="cuda")
-    tr.gain_field(fields, gain, gp, change)
+    tr.gain_field(fields, gain, gp, change, scratch=scratch)
     K, want = gain.cpu().numpy(), setup["ogain"]
     scale = np.abs(want).max()
     assert scale > 1.0                       # a non-trivial gain (1/cm)
     assert np.abs(K - want).max() < TOL * scale
     ch = change.cpu().numpy()
     assert abs(ch[0] / ch[1] - 1.0) < 1e-12  # from zero: every |new - old| is |new|
+    if not symmetric:
+        assert np.array_equal(K, want)       # same sum order as the oracle: bit for bit
     assert abs(ch[1] / np.abs(want).sum() - 1.0) < 1e-9
     # the normalised fields: intensity and wave vectors; what beams exchange in a cell sums to zero
     nf = fields.cpu().numpy()
     inten = np.where(nf[0] > 0, nf[0], 0.0)
     exch = (inten * K).sum(axis=0)
-    assert np.abs(exch).max() <= 1e-12 * np.abs(inten * K).sum(axis=0).max()
+    assert np.abs(exch).max() <= 1e-11 * np.abs(inten * K).sum(axis=0).max()
     kmag = np.sqrt(nf[1] ** 2 + nf[2] ** 2 + nf[3] ** 2)
     present = setup["ofields"][0] > 0                 # where the beam deposited energy the entry is normalised
     d = tr.derived
@@ -124,7 +130,7 @@ def test_gain_field_matches_oracle_and_is_antisymmetric(api, oracle, setup, torc
     # under-relaxation: a second call with relax = 0.25 moves a quarter of the way towards the same K
     gain2 = torch_cuda.zeros_like(gain)
     fields2 = torch_cuda.from_numpy(setup["ofields"].copy()).cuda()
-    tr.gain_field(fields2, gain2, api.default_gain_params(relax=0.25), None)
+    tr.gain_field(fields2, gain2, api.default_gain_params(relax=0.25), None, scratch=scratch)
     assert np.abs(gain2.cpu().numpy() - 0.25 * K).max() < 1e-12 * scale
 
 
