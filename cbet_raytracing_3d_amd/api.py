@@ -111,7 +111,7 @@ EXPORTS = [
     "cbet_safeGPUAlloc", "cbet_moveToAndFromGPU", "cbet_gpuFree",
     "cbet_context_create", "cbet_context_destroy", "cbet_context_counters", "cbet_context_tables",
     "cbet_launch_ray_XYZ", "cbet_tabulate_plasma", "cbet_trace_nodes", "cbet_ray_tracing",
-    "cbet_write_text", "cbet_edep_average", "cbet_debug_bounds_violations",
+    "cbet_write_text", "cbet_edep_average", "cbet_edep_average_device", "cbet_debug_bounds_violations",
     "cbet_gain_params_default", "cbet_gain_constants", "cbet_trace_cbet", "cbet_gain_field",
     "cbet_cbet_workspace_bytes", "cbet_cbet_solve",
 ]
@@ -164,6 +164,7 @@ def lib():
     L.cbet_write_text.argtypes = [dp, C.c_int, C.c_int, C.c_int, C.c_char_p]
     L.cbet_write_text.restype = C.c_longlong
     L.cbet_edep_average.argtypes = [dp, dp, C.c_int, C.c_int, C.c_int]
+    L.cbet_edep_average_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
     L.cbet_gain_params_default.argtypes = [C.POINTER(GainParams)]
     L.cbet_gain_constants.argtypes = [C.POINTER(Params), C.POINTER(GainParams), dp, dp, dp]
     L.cbet_trace_cbet.argtypes = [C.c_int, C.c_uint, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp,
@@ -452,6 +453,11 @@ def edep_average(edep):
     out = np.zeros((nx, ny, nz))
     _check(lib().cbet_edep_average(_dptr(e), _dptr(out), nx, ny, nz))
     return out
+
+
+def edep_average_device(edep, out, nx, ny, nz, stream=None):
+    """main.cu:334-349 on the device: edep (n+2)^3 and out n^3 are device tensors / addresses."""
+    _check(lib().cbet_edep_average_device(_addr(edep), _addr(out), nx, ny, nz, _addr(stream)))
 
 
 def debug_bounds_violations(reset=True, stream=None):

@@ -655,6 +655,14 @@ int cbet_launch_ray_XYZ(int b, unsigned nindices, double *te_data_g, double *r_d
                             xconst, yconst, zconst, p, ctx, stream);
 }
 
+int cbet_edep_average_device(const double *edep, double *edepavg, int nx, int ny, int nz, void *stream)
+{
+    if (!edep || !edepavg || nx < 1 || ny < 1 || nz < 1) return fail(CBET_EINVAL, "cbet_edep_average_device: bad array");
+    if ((long)(nx + 2) * (ny + 2) * (nz + 2) >= (1L << 31)) return fail(CBET_EINVAL, "cbet_edep_average_device: grid too large");
+    CBET_HIP(launch_edep_average(edep, edepavg, nx, ny, nz, (hipStream_t)stream));
+    return CBET_OK;
+}
+
 // ---- CBET stage (parity unpinned -- see the header) ---------------------------
 static int validate_gain(const cbet_params *p, const cbet_gain_params *g)
 {

@@ -99,6 +99,7 @@ hipError_t audit_violations(unsigned long long *out, bool reset, hipStream_t str
 hipError_t launch_trace(const TraceArgs &a, int variant, int window_log2, int copies_log2, int prereduce,
                         bool corner_flip, bool two_boxes, bool force_idx64, hipStream_t stream);
 hipError_t launch_gain_field(const GainArgs &a, hipStream_t stream);
+hipError_t launch_edep_average(const double *edep, double *out, int nx, int ny, int nz, hipStream_t stream);
 
 }  // namespace cbet
 #endif

@@ -1377,6 +1377,47 @@ __global__ void __launch_bounds__(256) k_gain_field_sym(const GainArgs a)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// main.cu:334-349 (commented out there): edepavg[i][j][k] = (27 haloed cells around node (i,j,k)) / 27,
+// terms added in the order the reference writes them (i offset fastest, then j, then k).  A 4 x 4 x 64
+// output tile per workgroup, its 6 x 6 x 66 input block staged through LDS: HBM sees every input once.
+// ---------------------------------------------------------------------------------------------
+constexpr int kAvgTI = 4, kAvgTJ = 4, kAvgTK = 64, kAvgPad = kAvgTK + 3;
+
+__global__ void __launch_bounds__(256) k_edep_average(const double *__restrict__ edep, double *__restrict__ out,
+                                                      int nx, int ny, int nz)
+{
+    __shared__ double t[kAvgTI + 2][kAvgTJ + 2][kAvgPad];
+    const int tk = (nz + kAvgTK - 1) / kAvgTK, tj = (ny + kAvgTJ - 1) / kAvgTJ;
+    const int bk = blockIdx.x % tk, bj = (blockIdx.x / tk) % tj, bi = blockIdx.x / (tk * tj);
+    const int i0 = bi * kAvgTI, j0 = bj * kAvgTJ, k0 = bk * kAvgTK;
+    const long sY = nz + 2, sX = (long)(ny + 2) * (nz + 2);
+    for (int idx = threadIdx.x; idx < (kAvgTI + 2) * (kAvgTJ + 2) * (kAvgTK + 2); idx += blockDim.x) {
+        const int c = idx % (kAvgTK + 2), b = (idx / (kAvgTK + 2)) % (kAvgTJ + 2), a = idx / ((kAvgTK + 2) * (kAvgTJ + 2));
+        const int gi = i0 + a, gj = j0 + b, gk = k0 + c;
+        t[a][b][c] = (gi < nx + 2 && gj < ny + 2 && gk < nz + 2) ? edep[gi * sX + gj * sY + gk] : 0.0;
+    }
+    __syncthreads();
+    const int lk = threadIdx.x & (kAvgTK - 1), lj = threadIdx.x / kAvgTK;
+    const int j = j0 + lj, k = k0 + lk;
+    if (j >= ny || k >= nz) return;
+#pragma unroll
+    for (int li = 0; li < kAvgTI; ++li) {
+        const int i = i0 + li;
+        if (i >= nx) break;
+        double acc = t[li][lj][lk];
+#pragma unroll
+        for (int dk = 0; dk < 3; ++dk)
+#pragma unroll
+            for (int dj = 0; dj < 3; ++dj)
+#pragma unroll
+                for (int di = 0; di < 3; ++di)
+                    if (dk + dj + di != 0) acc = acc + t[li + di][lj + dj][lk + dk];
+        out[((long)i * ny + j) * nz + k] = acc / 27;
+    }
+}
+
 }  // namespace
 
 hipError_t launch_tabulate(const TabulateArgs &a, hipStream_t stream)
@@ -1446,6 +1487,13 @@ static void dispatch_trace(const TraceArgs &a, int variant, int wl, int rl, int 
         default: launch_k<3, 3, 2, 2, false, false, IDX64>(a, grid, stream); break;
         }
     }
+}
+
+hipError_t launch_edep_average(const double *edep, double *out, int nx, int ny, int nz, hipStream_t stream)
+{
+    const long blocks = (long)((nx + kAvgTI - 1) / kAvgTI) * ((ny + kAvgTJ - 1) / kAvgTJ) * ((nz + kAvgTK - 1) / kAvgTK);
+    hipLaunchKernelGGL(k_edep_average, dim3((unsigned)blocks), dim3(256), 0, stream, edep, out, nx, ny, nz);
+    return hipGetLastError();
 }
 
 hipError_t launch_gain_field(const GainArgs &a, hipStream_t stream)

@@ -253,6 +253,8 @@ long long cbet_write_text(const double *edep, int d0, int d1, int d2, const char
  * edepavg[nx][ny][nz] from the haloed HOST array edep[nx+2][ny+2][nz+2], same summation order.
  */
 int cbet_edep_average(const double *edep, double *edepavg, int nx, int ny, int nz);
+/* The same on the current device: edep and edepavg are DEVICE arrays; enqueued on `stream`, same bits. */
+int cbet_edep_average_device(const double *edep, double *edepavg, int nx, int ny, int nz, void *stream);
 
 /* ---- CBET stage ------------------------------------------------------------- */
 /*

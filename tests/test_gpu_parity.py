@@ -583,3 +583,37 @@ def test_pass_is_hip_graph_capturable(api, oracle, inputs, torch_cuda):
     assert parity_err(e.cpu().numpy(), oe) < PARITY_TOL
     del graph
     tr.close()
+
+
+def test_edep_average_on_device_equals_host(api, inputs, torch_cuda):
+    """main.cu:334-349 as a kernel: the 27-point node average, bit for bit the host routine's (same
+    summation order), on a ragged grid and on a real deposition grid; and its HBM rate at 256^3."""
+    rng = np.random.default_rng(5)
+    for (nx, ny, nz) in ((5, 7, 70), (33, 18, 129)):
+        e = rng.standard_normal((nx + 2, ny + 2, nz + 2)) * 10.0 ** rng.integers(-3, 12, size=(nx + 2, ny + 2, nz + 2))
+        d_e = torch_cuda.from_numpy(e).cuda()
+        d_o = torch_cuda.full((nx, ny, nz), float("nan"), dtype=torch_cuda.float64, device="cuda")
+        api.edep_average_device(d_e, d_o, nx, ny, nz, torch_cuda.cuda.current_stream().cuda_stream)
+        assert np.array_equal(d_o.cpu().numpy(), api.edep_average(e))
+    n = 256
+    tr = make_tracer(api, inputs, n)
+    e = tr.new_grid()
+    tr.launch(e)
+    out = torch_cuda.empty((n, n, n), dtype=torch_cuda.float64, device="cuda")
+    stream = torch_cuda.cuda.current_stream().cuda_stream
+    api.edep_average_device(e, out, n, n, n, stream)
+    a, b = torch_cuda.cuda.Event(enable_timing=True), torch_cuda.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(20):
+        api.edep_average_device(e, out, n, n, n, stream)
+    b.record()
+    torch_cuda.cuda.synchronize()
+    ms = a.elapsed_time(b) / 20
+    gbs = (e.numel() + out.numel()) * 8 / (ms * 1e-3) / 1e9
+    print("k_edep_average 256^3: %.3f ms, %.0f GB/s of algorithmic traffic" % (ms, gbs))
+    host = api.edep_average(e.cpu().numpy())
+    assert np.array_equal(out.cpu().numpy(), host)
+    assert gbs > 1000.0
+    tr.close()
+    with pytest.raises(api.CbetError):
+        api.edep_average_device(e, out, 0, n, n, stream)
