@@ -211,3 +211,32 @@ def test_sharded_iteration_equals_unsharded(tmp_path, api, oracle):
     assert np.abs(got["gain"] - gain).max() < 1e-9 * np.abs(gain).max()
     assert np.abs(got["beam_gain"] - rep["beam_gain"]).max() < 1e-9 * np.abs(rep["beam_gain"]).max()
     assert float(got["imbalance"]) < 1e-3 and rep["imbalance"] < 1e-3
+
+
+def test_two_mirror_beams_exchange_nothing_net(oracle, inputs):
+    """SURVEY 8(f) f1's suggested check: two beams that are mirror images of each other in a mirror-symmetric
+    plasma and flow must end up with equal energy, so neither gains at the other's expense.  On a grid the
+    symmetry holds to O(dx) (launch coordinates, nearest-node sampling and the deposit stencil are not mirror
+    symmetric), so the net gain shrinks against the locally exchanged energy as the grid is refined; the two
+    gains cancel to rounding at any resolution."""
+    _, r, ne, te = inputs
+    b = np.array([[0.35, 0.25, 0.90], [0.35, 0.25, -0.90]])
+    b /= np.linalg.norm(b, axis=1)[:, None]
+    g = oracle.gain_default()
+    ratio = {}
+    for n in (32, 48):
+        cfg = oracle.default_config(n, nbeams=2)
+        ne3d, kap = oracle.node_tables(cfg, r, ne, te)
+        K = None
+        for it in range(10):
+            F = np.stack([oracle.trace_cbet(cfg, g, b, ne3d, kap, gain=K, quantity=q, per_beam=True, nthreads=NCPU)[0]
+                          for q in (1, 2, 3, 4)])
+            K, ch = oracle.gain_field(cfg, g, F, ne3d, relax=1.0, gain=K, nthreads=NCPU)
+            if ch[0] / ch[1] < 1e-8:
+                break
+        _, _, bg = oracle.trace_cbet(cfg, g, b, ne3d, kap, gain=K, nthreads=NCPU)
+        exchanged = np.abs(F[0] * K).sum(axis=(1, 2, 3))
+        assert exchanged[0] > 1e12 and abs(exchanged[0] / exchanged[1] - 1) < 1e-9   # the same energy changes hands both ways
+        assert abs(bg.sum()) < 1e-6 * np.abs(bg).sum()                                # conservation
+        ratio[n] = np.abs(bg).max() / exchanged.max()
+    assert ratio[32] < 0.15 and ratio[48] < 0.02 and ratio[48] < ratio[32]
