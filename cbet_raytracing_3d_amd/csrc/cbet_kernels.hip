@@ -1542,7 +1542,9 @@ hipError_t launch_trace(const TraceArgs &a, int variant, int window_log2, int co
     TraceArgs b = a;
     b.xcd_chunk = (int)chunk;
     const dim3 grid((unsigned)(chunk > 0 ? chunk * 8 : waves));
-    const bool idx64 = force_idx64 || (unsigned long long)a.nx * a.ny * a.nz * 8ull >= (1ull << 32);
+    // 32-bit byte offsets into the node tables -- and, with the CBET hooks, into a beam's haloed gain grid
+    const unsigned long long table_bytes = 8ull * (a.gain ? (unsigned long long)a.hsize : (unsigned long long)a.nx * a.ny * a.nz);
+    const bool idx64 = force_idx64 || table_bytes >= (1ull << 32);
     // the pre-reduction key packs (flat haloed node index << 3 | signs) into 31 bits
     if ((long)(a.nx + 2) * (a.ny + 2) * (a.nz + 2) >= (1L << 28)) prereduce = 0;
     const bool flip = prereduce == 0 && corner_flip;

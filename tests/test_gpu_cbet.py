@@ -209,3 +209,22 @@ def test_cbet_argument_errors(api, setup, torch_cuda):
         api.cbet_solve(tr.d_te, tr.d_r, tr.d_ne, e, tr.d_bbeam_norm, tr.d_beam_norm, tr.d_pow_r, tr.d_phase_r,
                        tr.params.copy(shard_index=0, shard_count=2), setup["gp"], ctx=tr.ctx)
     assert ei.value.code == api.EINVAL
+
+
+def test_cbet_wide_index_path(api, inputs, setup, torch_cuda):
+    """64-bit gathers (grids of 4 GB and more) with the CBET hooks: forced on a small grid, same results."""
+    from cbet_raytracing_3d_amd.tracer import RayTracer
+    bn, r, ne, te = inputs
+    trw = RayTracer(api.default_params(N, nbeams=len(BEAMS), force_wide_index=1), r, ne, te, beam_norm=bn[BEAMS])
+    trw.tabulate()
+    tr, gp = setup["tr"], setup["gp"]
+    gain = torch_cuda.from_numpy(setup["ogain"].copy()).cuda()
+    fw, f = trw.new_fields(), tr.new_fields()
+    trw.launch_cbet(fw, gp, fields=True, gain=gain)
+    tr.launch_cbet(f, gp, fields=True, gain=gain)
+    assert parity_err(fw.cpu().numpy().reshape(-1), f.cpu().numpy().reshape(-1)) < TOL
+    ew, e = trw.new_grid(), tr.new_grid()
+    trw.launch_cbet(ew, gp, gain=gain)
+    tr.launch_cbet(e, gp, gain=gain)
+    assert parity_err(ew.cpu().numpy(), e.cpu().numpy()) < TOL
+    trw.close()
