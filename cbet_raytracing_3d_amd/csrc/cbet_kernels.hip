@@ -203,6 +203,7 @@ __device__ __forceinline__ bool launch_ray(const TraceArgs &a, int beam, int pre
 // LDS accumulate is range-checked; a violation is counted and the access skipped.  Never shipped.
 __device__ const double *g_audit_edep_lo, *g_audit_edep_hi;
 __device__ unsigned long long g_audit_nodes;
+__device__ unsigned long long g_audit_hsize;   // CBET hooks: entries of a beam's haloed gain grid
 __device__ unsigned long long g_audit_violations;
 __device__ __forceinline__ bool audit_fail() { atomicAdd(&g_audit_violations, 1ull); return true; }
 #define CBET_AUDIT(cond) ((cond) || !audit_fail())
@@ -531,6 +532,17 @@ __device__ __forceinline__ double node_load(const double *base, unsigned idx)
     return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + (idx * 8u));
 }
 
+// The same gather from a beam's haloed gain grid (CBET hooks); only the audited range differs.
+template <bool IDX64>
+__device__ __forceinline__ double gain_load(const double *base, unsigned idx)
+{
+#ifdef CBET_DEBUG_BOUNDS
+    if (!(idx < g_audit_hsize)) { audit_fail(); return 0.0; }
+#endif
+    if (IDX64) return base[idx];
+    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + (idx * 8u));
+}
+
 // ---------------------------------------------------------------------------------------------
 // The ray integrator.
 //   DEPOSIT 1: 8 global atomics per step   2: tagged LDS window   3: dense moving LDS window
@@ -843,10 +855,10 @@ __global__ void __launch_bounds__(kWave) k_trace(const TraceArgs a)
                     // K at the eight deposit nodes, weighted like the deposit.  The pairwise tree makes the
                     // sum independent of the corner order (FLIP swaps operands of commutative adds only).
                     const int nX0 = __mul24(X0, sXh), nX1 = __mul24(X1, sXh), nY0 = __mul24(Y0, sYh), nY1 = __mul24(Y1, sYh);
-                    const double g0 = node_load<IDX64>(gk, (unsigned)(nX0 + nY0 + Z0)), g1 = node_load<IDX64>(gk, (unsigned)(nX1 + nY0 + Z0));
-                    const double g2 = node_load<IDX64>(gk, (unsigned)(nX0 + nY0 + Z1)), g3 = node_load<IDX64>(gk, (unsigned)(nX1 + nY0 + Z1));
-                    const double g4 = node_load<IDX64>(gk, (unsigned)(nX0 + nY1 + Z0)), g5 = node_load<IDX64>(gk, (unsigned)(nX1 + nY1 + Z0));
-                    const double g6 = node_load<IDX64>(gk, (unsigned)(nX0 + nY1 + Z1)), g7 = node_load<IDX64>(gk, (unsigned)(nX1 + nY1 + Z1));
+                    const double g0 = gain_load<IDX64>(gk, (unsigned)(nX0 + nY0 + Z0)), g1 = gain_load<IDX64>(gk, (unsigned)(nX1 + nY0 + Z0));
+                    const double g2 = gain_load<IDX64>(gk, (unsigned)(nX0 + nY0 + Z1)), g3 = gain_load<IDX64>(gk, (unsigned)(nX1 + nY0 + Z1));
+                    const double g4 = gain_load<IDX64>(gk, (unsigned)(nX0 + nY1 + Z0)), g5 = gain_load<IDX64>(gk, (unsigned)(nX1 + nY1 + Z0));
+                    const double g6 = gain_load<IDX64>(gk, (unsigned)(nX0 + nY1 + Z1)), g7 = gain_load<IDX64>(gk, (unsigned)(nX1 + nY1 + Z1));
                     const double k01 = wgt[0] * g0 + wgt[1] * g1, k23 = wgt[2] * g2 + wgt[3] * g3;
                     const double k45 = wgt[4] * g4 + wgt[5] * g5, k67 = wgt[6] * g6 + wgt[7] * g7;
                     double x = ((k01 + k23) + (k45 + k67)) * ds;
@@ -1532,7 +1544,9 @@ hipError_t launch_trace(const TraceArgs &a, int variant, int window_log2, int co
     {
         const long cells = (long)(a.nx + 2) * (a.ny + 2) * (a.nz + 2);
         const double *lo = a.edep, *hi = a.edep + (a.grid_stride ? a.grid_stride * (long)(a.beam_lo + a.nbeams_local) : cells);
-        const unsigned long long nodes = (unsigned long long)a.nx * a.ny * a.nz;
+        if (a.quantity != 0) hi = a.edep + 4 * a.comp_stride;   // the field pass writes four component arrays
+        const unsigned long long nodes = (unsigned long long)a.nx * a.ny * a.nz, hs = (unsigned long long)a.hsize;
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_audit_hsize), &hs, sizeof hs, 0, hipMemcpyHostToDevice, stream);
         (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_audit_edep_lo), &lo, sizeof lo, 0, hipMemcpyHostToDevice, stream);
         (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_audit_edep_hi), &hi, sizeof hi, 0, hipMemcpyHostToDevice, stream);
         (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_audit_nodes), &nodes, sizeof nodes, 0, hipMemcpyHostToDevice, stream);

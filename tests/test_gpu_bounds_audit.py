@@ -46,7 +46,37 @@ for nx, ny, nz, rpz, beams, absorb in cases:
         out.append(dict(case=[nx, ny, nz, rpz, len(beams), absorb], variant=variant, violations=viol,
                         steps=int(c.ray_steps), osteps=int(osteps), err=err))
         tr.close()
+# the CBET hooks through the same audit: fused field pass and deposition pass with a gain field
+cbet = []
+for nx, ny, nz, rpz, beams in [(3, 3, 3, 4, [0, 30]), (9, 7, 13, 5, [10, 50, 20]), (33, 20, 27, 3, [7, 22, 37, 52])]:
+    p = api.default_params(nx, nbeams=len(beams), rays_per_zone=rpz)
+    p.ny, p.nz = ny, nz
+    tr = RayTracer(p, r, ne, te, beam_norm=bn[beams])
+    tr.tabulate()
+    gp = api.default_gain_params()
+    cfg = O.default_config(nx, nbeams=len(beams), rays_per_zone=rpz)
+    cfg.ny, cfg.nz = ny, nz
+    ne3d, kap = O.node_tables(cfg, r, ne, te)
+    rng = np.random.default_rng(nx)
+    gain = rng.uniform(-40.0, 40.0, size=(len(beams), nx + 2, ny + 2, nz + 2))
+    d_gain = torch.from_numpy(gain).cuda()
+    f = tr.new_fields(); tr.counters(reset=True)
+    tr.launch_cbet(f, gp, fields=True, gain=d_gain)
+    e = tr.new_grid()
+    tr.launch_cbet(e, gp, gain=d_gain)
+    c = tr.counters(reset=True)
+    viol = api.debug_bounds_violations(reset=True)
+    og = O.gain_default()
+    of = np.stack([O.trace_cbet(cfg, og, bn[beams].copy(), ne3d, kap, gain=gain, quantity=q, per_beam=True, nthreads=8)[0]
+                   for q in (1, 2, 3, 4)])
+    oe, osteps, _ = O.trace_cbet(cfg, og, bn[beams].copy(), ne3d, kap, gain=gain, nthreads=8)
+    scale = max(np.abs(of).max(), 1e-300)
+    cbet.append(dict(case=[nx, ny, nz, rpz, len(beams)], violations=viol, steps=int(c.ray_steps), osteps=2 * int(osteps),
+                     err_fields=float(np.abs(f.cpu().numpy() - of).max() / scale),
+                     err_edep=parity_err(e.cpu().numpy(), oe) if np.abs(oe).max() > 0 else 0.0))
+    tr.close()
 print("RESULT " + json.dumps(out))
+print("CBET " + json.dumps(cbet))
 '''
 
 
@@ -68,6 +98,12 @@ def test_edge_geometries_in_bounds_audited_build(tmp_path):
         assert res["violations"] == 0, res
         assert res["steps"] == res["osteps"], res
         assert res["err"] < 1e-9, res
+    cbet = json.loads([l for l in run.stdout.splitlines() if l.startswith("CBET ")][-1][len("CBET "):])
+    assert len(cbet) == 3
+    for res in cbet:   # the CBET hooks: gain gathers, four-component tiles and flushes
+        assert res["violations"] == 0, res
+        assert res["steps"] == res["osteps"], res
+        assert res["err_fields"] < 1e-9 and res["err_edep"] < 1e-9, res
 
 
 def test_regular_build_reports_no_audit(tmp_path):
