@@ -9,6 +9,6 @@ build /tmp/libcbet_noflush.so -DCBET_EXPERIMENT_DROP_FLUSH_ATOMICS || exit 1
 build /tmp/libcbet_nomiss.so -DCBET_EXPERIMENT_DROP_MISS_ATOMICS || exit 1
 build /tmp/libcbet_noatomics.so -DCBET_EXPERIMENT_DROP_FLUSH_ATOMICS -DCBET_EXPERIMENT_DROP_MISS_ATOMICS || exit 1
 for lib in "" /tmp/libcbet_noflush.so /tmp/libcbet_nomiss.so /tmp/libcbet_noatomics.so; do
-  CBET_LIB_PATH=$lib timeout -k 10 200 python bench.py --steps 5 --warmup 1 --no-cpu-baseline 2>/dev/null | \
+  CBET_LIB_PATH=$lib timeout -k 10 200 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-cbet 2>/dev/null | \
     python3 -c "import sys,json; d=json.load(sys.stdin); print('lib=${lib:-shipped} (default config)', 'kernel_ms %.2f'%d['roofline']['kernel_ms'])"
 done

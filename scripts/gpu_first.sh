@@ -15,12 +15,12 @@ timeout -k 10 900 python -m pytest tests -m gpu -q -s -x > "$OUT/pytest.log" 2>&
 rc=$?; echo "pytest rc=$rc"; tail -25 "$OUT/pytest.log"; ok $rc || exit $rc
 
 for v in 1 2; do
-  timeout -k 10 300 python bench.py --steps 3 --warmup 1 --variant $v --no-cpu-baseline > "$OUT/bench_v$v.json" 2> "$OUT/bench_v$v.err"
+  timeout -k 10 300 python bench.py --steps 3 --warmup 1 --variant $v --no-cpu-baseline --no-cbet > "$OUT/bench_v$v.json" 2> "$OUT/bench_v$v.err"
   rc=$?; echo "bench v$v rc=$rc"; cat "$OUT/bench_v$v.json"; tail -3 "$OUT/bench_v$v.err"; ok $rc || exit $rc
 done
-timeout -k 10 300 python bench.py --steps 3 --warmup 1 --variant 2 --window 4 --no-cpu-baseline > "$OUT/bench_v2w4.json" 2> "$OUT/bench_v2w4.err"
+timeout -k 10 300 python bench.py --steps 3 --warmup 1 --variant 2 --window 4 --no-cpu-baseline --no-cbet > "$OUT/bench_v2w4.json" 2> "$OUT/bench_v2w4.err"
 rc=$?; echo "bench v2 w4 rc=$rc"; cat "$OUT/bench_v2w4.json"; ok $rc || exit $rc
 
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/prof.log" 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-cbet > "$OUT/prof.log" 2>&1
 rc=$?; echo "rocprof rc=$rc"; tail -3 "$OUT/prof.log"
 find "$OUT/prof" -name "*stats*" | head

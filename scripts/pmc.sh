@@ -11,7 +11,7 @@ i=0
 while read -r set; do
   [ -z "$set" ] && continue
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d "$OUT/p$i" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > "$OUT/p$i.log" 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d "$OUT/p$i" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-cbet "$@" > "$OUT/p$i.log" 2>&1
   rc=$?; echo "pass $i [$set] rc=$rc"
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit $rc; fi
 done <<'SETS'
