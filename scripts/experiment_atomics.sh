@@ -4,7 +4,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 C=cbet_raytracing_3d_amd/csrc
-build() { hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared "${@:2}" -I include -I $C -o "$1" $C/cbet_kernels.hip $C/cbet_abi.cpp $C/cbet_host.cpp $C/cbet_output.cpp -lrccl; }
+build() { hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared "${@:2}" -I include -I $C -o "$1" $C/*.hip $C/*.cpp -lrccl; }
 build /tmp/libcbet_noflush.so -DCBET_EXPERIMENT_DROP_FLUSH_ATOMICS || exit 1
 build /tmp/libcbet_nomiss.so -DCBET_EXPERIMENT_DROP_MISS_ATOMICS || exit 1
 build /tmp/libcbet_noatomics.so -DCBET_EXPERIMENT_DROP_FLUSH_ATOMICS -DCBET_EXPERIMENT_DROP_MISS_ATOMICS || exit 1

@@ -83,7 +83,7 @@ print("CBET " + json.dumps(cbet))
 def test_edge_geometries_in_bounds_audited_build(tmp_path):
     csrc = os.path.join(ROOT, "cbet_raytracing_3d_amd", "csrc")
     lib = str(tmp_path / "libcbet_audit.so")
-    srcs = [os.path.join(csrc, f) for f in ("cbet_kernels.hip", "cbet_abi.cpp", "cbet_host.cpp", "cbet_output.cpp")]
+    srcs = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".cpp")))
     subprocess.check_call(["hipcc", "-O2", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC",
                            "-shared", "-DCBET_DEBUG_BOUNDS", "-I", os.path.join(ROOT, "include"), "-I", csrc,
                            "-o", lib] + srcs + ["-lrccl"])
