@@ -111,7 +111,8 @@ EXPORTS = [
     "cbet_safeGPUAlloc", "cbet_moveToAndFromGPU", "cbet_gpuFree",
     "cbet_context_create", "cbet_context_destroy", "cbet_context_counters", "cbet_context_tables",
     "cbet_launch_ray_XYZ", "cbet_tabulate_plasma", "cbet_trace_nodes", "cbet_ray_tracing",
-    "cbet_write_text", "cbet_edep_average", "cbet_edep_average_device", "cbet_debug_bounds_violations",
+    "cbet_write_text", "cbet_edep_average", "cbet_edep_average_device", "cbet_node_coordinates", "cbet_write_npy",
+    "cbet_debug_bounds_violations",
     "cbet_gain_params_default", "cbet_gain_constants", "cbet_trace_cbet", "cbet_gain_field",
     "cbet_cbet_workspace_bytes", "cbet_cbet_solve",
 ]
@@ -165,6 +166,9 @@ def lib():
     L.cbet_write_text.restype = C.c_longlong
     L.cbet_edep_average.argtypes = [dp, dp, C.c_int, C.c_int, C.c_int]
     L.cbet_edep_average_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    L.cbet_node_coordinates.argtypes = [C.POINTER(Params), dp, dp, dp]
+    L.cbet_write_npy.argtypes = [dp, C.c_int, C.POINTER(C.c_long), C.c_char_p]
+    L.cbet_write_npy.restype = C.c_longlong
     L.cbet_gain_params_default.argtypes = [C.POINTER(GainParams)]
     L.cbet_gain_constants.argtypes = [C.POINTER(Params), C.POINTER(GainParams), dp, dp, dp]
     L.cbet_trace_cbet.argtypes = [C.c_int, C.c_uint, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp,
@@ -453,6 +457,24 @@ def edep_average(edep):
     out = np.zeros((nx, ny, nz))
     _check(lib().cbet_edep_average(_dptr(e), _dptr(out), nx, ny, nz))
     return out
+
+
+def node_coordinates(params):
+    """main.cu:321-332: (x, y, z), each [nx][ny][nz]."""
+    shape = (params.nx, params.ny, params.nz)
+    x, y, z = np.empty(shape), np.empty(shape), np.empty(shape)
+    _check(lib().cbet_node_coordinates(C.byref(params), _dptr(x), _dptr(y), _dptr(z)))
+    return x, y, z
+
+
+def write_npy(array, path):
+    """The library's .npy writer (stand-in for the reference's dead HDF5 output); returns bytes written."""
+    a = np.ascontiguousarray(array, dtype=np.float64)
+    shape = (C.c_long * a.ndim)(*a.shape)
+    n = lib().cbet_write_npy(_dptr(a), a.ndim, shape, os.fsencode(path))
+    if n < 0:
+        _check(int(n))
+    return int(n)
 
 
 def edep_average_device(edep, out, nx, ny, nz, stream=None):

@@ -98,3 +98,54 @@ extern "C" int cbet_edep_average(const double *edep, double *edepavg, int nx, in
             }
     return CBET_OK;
 }
+
+// main.cu:321-332 (commented out there): the node coordinate arrays x[i][j][k] = i*dx + xmin, ...
+extern "C" int cbet_node_coordinates(const cbet_params *p, double *x, double *y, double *z)
+{
+    cbet_derived d;
+    if (int rc = cbet_derive(p, &d)) return rc;
+    if (!x || !y || !z) return cbet::fail(CBET_EINVAL, "cbet_node_coordinates: NULL array");
+    for (int i = 0; i < p->nx; ++i)
+        for (int j = 0; j < p->ny; ++j)
+            for (int k = 0; k < p->nz; ++k) {
+                const long o = ((long)i * p->ny + j) * p->nz + k;
+                x[o] = i * d.dx + p->xmin;
+                y[o] = j * d.dy + p->ymin;
+                z[o] = k * d.dz + p->zmin;
+            }
+    return CBET_OK;
+}
+
+// The reference's binary output is save2Hdf5 (main.cu:37-94: /Coordinate_x,y,z and /Edepavg as
+// [nx][ny][nz] little-endian fp64), dead code there and dependent on libhdf5, which this image does not
+// have.  The same arrays can be written as NumPy .npy files instead (format 1.0: magic, header length,
+// a Python-literal header padded to a 64-byte boundary, then the C-order little-endian data).
+extern "C" long long cbet_write_npy(const double *data, int ndim, const long *shape, const char *path)
+{
+    if (!data || !shape || !path || ndim < 1 || ndim > 8) return cbet::fail(CBET_EINVAL, "cbet_write_npy: bad arguments");
+    long long count = 1;
+    char dims[256];
+    size_t used = 0;
+    for (int a = 0; a < ndim; ++a) {
+        if (shape[a] < 0) return cbet::fail(CBET_EINVAL, "cbet_write_npy: negative extent");
+        count *= shape[a];
+        used += (size_t)std::snprintf(dims + used, sizeof dims - used, "%ld,%s", shape[a], a + 1 < ndim ? " " : "");
+    }
+    if (ndim > 1) dims[used - 1] = '\0';   // "(3, 4,)" is legal Python but numpy writes "(3, 4)"
+    char header[512];
+    int len = std::snprintf(header, sizeof header, "{'descr': '<f8', 'fortran_order': False, 'shape': (%s), }", dims);
+    const int unpadded = 10 + len + 1;                       // magic(6) + version(2) + header length(2) + text + '\n'
+    const int pad = (64 - unpadded % 64) % 64;
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return cbet::fail(CBET_EINVAL, "cbet_write_npy: cannot open %s", path);
+    const unsigned char magic[8] = {0x93, 'N', 'U', 'M', 'P', 'Y', 1, 0};
+    const unsigned hlen = (unsigned)(len + pad + 1);
+    const unsigned char hl[2] = {(unsigned char)(hlen & 0xFF), (unsigned char)(hlen >> 8)};
+    bool ok = std::fwrite(magic, 1, 8, f) == 8 && std::fwrite(hl, 1, 2, f) == 2 && std::fwrite(header, 1, (size_t)len, f) == (size_t)len;
+    for (int i = 0; ok && i < pad; ++i) ok = std::fputc(' ', f) != EOF;
+    ok = ok && std::fputc('\n', f) != EOF;
+    ok = ok && std::fwrite(data, sizeof(double), (size_t)count, f) == (size_t)count;
+    ok = (std::fclose(f) == 0) && ok;
+    if (!ok) return cbet::fail(CBET_EINVAL, "cbet_write_npy: short write to %s", path);
+    return 10 + (long long)hlen + count * (long long)sizeof(double);
+}

@@ -255,6 +255,15 @@ long long cbet_write_text(const double *edep, int d0, int d1, int d2, const char
 int cbet_edep_average(const double *edep, double *edepavg, int nx, int ny, int nz);
 /* The same on the current device: edep and edepavg are DEVICE arrays; enqueued on `stream`, same bits. */
 int cbet_edep_average_device(const double *edep, double *edepavg, int nx, int ny, int nz, void *stream);
+/* main.cu:321-332 (commented out in the reference): HOST arrays x, y, z of [nx][ny][nz] node coordinates. */
+int cbet_node_coordinates(const cbet_params *p, double *x, double *y, double *z);
+/*
+ * Binary output.  The reference's is save2Hdf5 (main.cu:37-94: /Coordinate_x,y,z and /Edepavg, [nx][ny][nz]
+ * little-endian fp64) -- dead code there, and libhdf5 does not exist in this image.  The same HOST arrays
+ * can be written as NumPy .npy files (format 1.0, C order, '<f8'): data[shape[0]]...[shape[ndim-1]].
+ * Returns the number of bytes written, or a negative CBET_E* code.
+ */
+long long cbet_write_npy(const double *data, int ndim, const long *shape, const char *path);
 
 /* ---- CBET stage ------------------------------------------------------------- */
 /*

@@ -203,3 +203,25 @@ def test_edep_average(api):
                 v = e[2 + di, 3 + dj, 1 + dk]
                 acc = v if acc is None else acc + v
     assert got[2, 3, 1] == acc / 27
+
+
+def test_npy_writer_and_node_coordinates(api, tmp_path):
+    """The .npy stand-in for the reference's (dead) HDF5 output: numpy must read back what the library wrote,
+    for shapes whose header lengths exercise the 64-byte padding; coordinates as main.cu:321-332."""
+    rng = np.random.default_rng(3)
+    for shape in ((7,), (3, 4), (2, 3, 5), (11, 1, 13), (1, 1, 1, 2), (100000,)):
+        a = rng.standard_normal(shape)
+        path = tmp_path / ("a_%s.npy" % "x".join(map(str, shape)))
+        n = api.write_npy(a, str(path))
+        assert n == os.path.getsize(path) and (n - a.nbytes) % 64 == 0
+        b = np.load(path)
+        assert b.dtype == np.float64 and b.shape == shape and np.array_equal(a, b) and b.flags["C_CONTIGUOUS"]
+    with pytest.raises(api.CbetError):
+        api.write_npy(np.zeros(3), str(tmp_path / "no_such_dir" / "a.npy"))
+    p = api.default_params(6)
+    p.ny, p.nz = 4, 5
+    x, y, z = api.node_coordinates(p)
+    d = api.derive(p)
+    assert x.shape == (6, 4, 5)
+    assert np.array_equal(x[:, 2, 3], np.arange(6) * d.dx + p.xmin) and np.array_equal(y[1, :, 0], np.arange(4) * d.dy + p.ymin)
+    assert np.array_equal(z[5, 3, :], np.arange(5) * d.dz + p.zmin)

@@ -617,3 +617,34 @@ def test_edep_average_on_device_equals_host(api, inputs, torch_cuda):
     tr.close()
     with pytest.raises(api.CbetError):
         api.edep_average_device(e, out, 0, n, n, stream)
+
+
+def test_cli_binary_output_and_cbet_mode(tmp_path):
+    """cbet-gpu --npy: what the reference's (dead) save2Hdf5 would have stored -- Coordinate_x/y/z and Edepavg
+    [n][n][n] (main.cu:37-94, 321-351) -- plus the haloed edep, as .npy files numpy reads back; and
+    --cbet, the CBET iteration behind the same command line."""
+    import subprocess
+    from cbet_raytracing_3d_amd import api, build
+    from conftest import ROOT
+    exe, n = build.CLI_PATH, 40
+    prefix = str(tmp_path / "run")
+    out = subprocess.run([exe, "1", "--n", str(n), "--beams", "6", "--npy", prefix], cwd=ROOT, capture_output=True,
+                         timeout=300, text=True)
+    assert out.returncode == 0, out.stderr
+    edep = np.load(prefix + "_edep.npy")
+    avg = np.load(prefix + "_Edepavg.npy")
+    assert edep.shape == (n + 2,) * 3 and avg.shape == (n,) * 3 and edep.sum() > 0
+    assert np.array_equal(avg, api.edep_average(edep))
+    x, y, z = api.node_coordinates(api.default_params(n))
+    for name, want in (("x", x), ("y", y), ("z", z)):
+        assert np.array_equal(np.load(prefix + "_Coordinate_%s.npy" % name), want)
+    steps_plain = int(out.stdout.split("ray-steps ")[1].split()[0])
+    out = subprocess.run([exe, "1", "--n", str(n), "--beams", "6", "--cbet", "--npy", prefix + "_cbet"], cwd=ROOT,
+                         capture_output=True, timeout=300, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "converged 1" in out.stdout
+    e2 = np.load(prefix + "_cbet_edep.npy")
+    ratio = e2.sum() / edep.sum()
+    assert 0.8 < ratio < 1.2 and abs(ratio - 1) > 1e-4       # the exchange changes what is absorbed, moderately
+    final = int(out.stdout.split("final pass ")[1].split(")")[0])
+    assert abs(final - steps_plain) < 0.05 * steps_plain

@@ -1,10 +1,12 @@
 // cbet-gpu -- run-time-configured driver with the reference's command line and stdout contract
 // (/root/reference/main.cu:234-357):
-//     cbet-gpu [omp_threads] [--n N] [--gpus G] [--beams B] [--print] [--data DIR] [--cbet]
+//     cbet-gpu [omp_threads] [--n N] [--gpus G] [--beams B] [--print] [--data DIR] [--cbet] [--npy PREFIX]
 // Without --print it prints the four phase timers in main.cu:225-230's format; with --print it
 // writes the -D PRINT text rendering of edep to stdout (what `make test` compares with truth_100).
 // --cbet runs the CBET fixed-point iteration (cbet_cbet_solve; parity unpinned, no reference counterpart) on
-// device 0 instead of the single reference pass.  Links only against the C ABI (libcbet_mi355x.so).
+// device 0 instead of the single reference pass.  --npy PREFIX writes what the reference's (dead) save2Hdf5 would
+// (main.cu:37-94: Coordinate_x/y/z and Edepavg, [n][n][n]) plus the haloed edep as PREFIX_*.npy files.
+// Links only against the C ABI (libcbet_mi355x.so).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -13,11 +15,28 @@
 
 #include "cbet_mi355x.h"
 
+// main.cu:321-351 + save2Hdf5 (:37-94), as .npy files
+static int write_binary(const std::string &prefix, const cbet_params &p, const std::vector<double> &edep)
+{
+    const size_t nodes = (size_t)p.nx * p.ny * p.nz;
+    std::vector<double> avg(nodes), x(nodes), y(nodes), z(nodes);
+    if (cbet_edep_average(edep.data(), avg.data(), p.nx, p.ny, p.nz) != CBET_OK ||
+        cbet_node_coordinates(&p, x.data(), y.data(), z.data()) != CBET_OK)
+        return 1;
+    const long inner[3] = {p.nx, p.ny, p.nz}, halo[3] = {p.nx + 2, p.ny + 2, p.nz + 2};
+    const struct { const char *name; const double *data; const long *shape; } out[] = {
+        {"Coordinate_x", x.data(), inner}, {"Coordinate_y", y.data(), inner}, {"Coordinate_z", z.data(), inner},
+        {"Edepavg", avg.data(), inner}, {"edep", edep.data(), halo}};
+    for (const auto &o : out)
+        if (cbet_write_npy(o.data, 3, o.shape, (prefix + "_" + o.name + ".npy").c_str()) < 0) return 1;
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     int n = 100, gpus = 1, beams = 60;
     bool print = false, cbet = false;
-    std::string data = "cbet_raytracing_3d_amd/data";
+    std::string data = "cbet_raytracing_3d_amd/data", npy;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         if (a == "--n" && i + 1 < argc) n = std::atoi(argv[++i]);
@@ -26,8 +45,9 @@ int main(int argc, char **argv)
         else if (a == "--data" && i + 1 < argc) data = argv[++i];
         else if (a == "--print") print = true;
         else if (a == "--cbet") cbet = true;
+        else if (a == "--npy" && i + 1 < argc) npy = argv[++i];
         else if (i == 1 && std::atoi(argv[1]) > 0) { /* argv[1] = OpenMP threads in the reference (main.cu:236-242); no host loops here */ }
-        else { std::fprintf(stderr, "usage: %s [omp_threads] [--n N] [--gpus G] [--beams B] [--print] [--data DIR] [--cbet]\n", argv[0]); return 2; }
+        else { std::fprintf(stderr, "usage: %s [omp_threads] [--n N] [--gpus G] [--beams B] [--print] [--data DIR] [--cbet] [--npy PREFIX]\n", argv[0]); return 2; }
     }
     cbet_params p;
     cbet_params_default(&p, n);
@@ -70,6 +90,7 @@ int main(int argc, char **argv)
             return 1;
         }
         for (auto &b : bufs) cbet_gpuFree(b.d, 0);
+        if (!npy.empty() && write_binary(npy, p, edep)) { std::fprintf(stderr, "%s\n", cbet_last_error()); return 1; }
         if (print) return cbet_write_text(edep.data(), p.nx + 2, p.ny + 2, p.nz + 2, nullptr) < 0;
         double sum = 0;
         for (double v : edep) sum += v;
@@ -83,6 +104,7 @@ int main(int argc, char **argv)
         std::fprintf(stderr, "%s\n", cbet_last_error());
         return 1;
     }
+    if (!npy.empty() && write_binary(npy, p, edep)) { std::fprintf(stderr, "%s\n", cbet_last_error()); return 1; }
     if (print) {
         if (cbet_write_text(edep.data(), p.nx + 2, p.ny + 2, p.nz + 2, nullptr) < 0) return 1;  // main.cu:353-355
     } else {
