@@ -19,7 +19,12 @@ e = tr.new_grid(); tr.counters(reset=True)
 tr.launch(e); torch.cuda.synchronize()
 c = tr.counters(reset=True)
 t0 = time.time()
-oe, osteps = O.trace(O.default_config(n), bn.copy(), r, ne, te, nthreads=threads)
+cfg = O.default_config(n)
+oe, osteps = np.zeros(O.grid_shape(cfg)), 0
+for lo in range(0, 60, 6):          # in chunks of beams, so a long run keeps reporting progress
+    _, st = O.trace(cfg, bn.copy(), r, ne, te, beam_lo=lo, beam_hi=lo + 6, nthreads=threads, edep=oe)
+    osteps += st
+    print("  oracle beams %d-%d done, %.0f s" % (lo, lo + 5, time.time() - t0), flush=True)
 print("oracle: %d ray-steps in %.1f s on %d threads" % (osteps, time.time() - t0, threads), flush=True)
 g = e.cpu().numpy()
 print("GPU: %d ray-steps; equal counts: %s" % (c.ray_steps, c.ray_steps == osteps))
