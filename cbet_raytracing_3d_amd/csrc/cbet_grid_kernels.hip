@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(256) k_gain_field(const GainArgs a)
 // to `scratch` (read-modify-write by the owning lane; the lines stay in L1/L2).  Half the pair
 // evaluations of k_gain_field and an eighth of its loads; sums are grouped by tile, so K differs
 // from the ordered kernel's in the last bits only.
-constexpr int GT = 6;
+constexpr int GT = 4;   // measured at 256^3, 60 beams: 2 -> 27.8 ms, 3 -> 22.5, 4 -> 20.8, 5 -> 23.2, 6 -> 22.7, 8 -> 34.8 (register pressure)
 
 struct BeamAtCell {
     double I, kx, ky, kz;
