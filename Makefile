@@ -24,6 +24,6 @@ test: cbet-gpu
 	     echo "PASS: $(TRUTH_100_BYTES) bytes, md5 $(TRUTH_100_MD5) (truth_100's pinned digest)"; fi
 
 clean:
-	$(RM) $(LIBDIR)/cbet-gpu $(LIBDIR)/libcbet_mi355x.so cbet_gpu_output oracle/libcbet_oracle.so
+	$(RM) $(LIBDIR)/cbet-gpu $(LIBDIR)/cbet-ref-shaped $(LIBDIR)/libcbet_mi355x.so cbet_gpu_output oracle/libcbet_oracle.so
 
 .PHONY: all cbet-gpu test clean

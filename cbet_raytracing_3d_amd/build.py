@@ -35,7 +35,9 @@ def is_stale():
         return True
     built = os.path.getmtime(LIB_PATH)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS + [os.path.abspath(__file__),
-                                                                os.path.join(ROOT, "tools", "cbet_gpu.cpp")]
+                                                                os.path.join(ROOT, "tools", "cbet_gpu.cpp"),
+                                                                os.path.join(ROOT, "tools", "cbet_reference_shaped.cpp"),
+                                                                os.path.join(ROOT, "include", "cbet_reference_api.hpp")]
     return any(os.path.getmtime(d) > built for d in deps)
 
 
@@ -50,6 +52,7 @@ def build(force=False, verbose=False, extra_flags=()):
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     build_cli(verbose)
+    build_ref_shaped(verbose)
     return LIB_PATH
 
 
@@ -65,6 +68,21 @@ def build_cli(verbose=False):
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     return CLI_PATH
+
+
+REF_SHAPED_PATH = os.path.join(PKG, "lib", "cbet-ref-shaped")
+
+
+def build_ref_shaped(verbose=False):
+    """tools/cbet_reference_shaped.cpp -> lib/cbet-ref-shaped: rayTracing()'s call sequence through the C++
+    overloads of include/cbet_reference_api.hpp (host-only code, compiled by hipcc for the HIP runtime API)."""
+    cmd = [hipcc(), "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tools", "cbet_reference_shaped.cpp"), "-o", REF_SHAPED_PATH,
+           "-L", LIB_DIR, "-lcbet_mi355x", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return REF_SHAPED_PATH
 
 
 if __name__ == "__main__":

@@ -648,3 +648,20 @@ def test_cli_binary_output_and_cbet_mode(tmp_path):
     assert 0.8 < ratio < 1.2 and abs(ratio - 1) > 1e-4       # the exchange changes what is absorbed, moderately
     final = int(out.stdout.split("final pass ")[1].split(")")[0])
     assert abs(final - steps_plain) < 0.05 * steps_plain
+
+
+def test_reference_shaped_driver_through_the_cpp_overloads():
+    """tools/cbet_reference_shaped.cpp: rayTracing()'s own call sequence (8 safeGPUAlloc, 7 moveToAndFromGPU,
+    launch_ray_XYZ with the reference's thirteen arguments, download, host sum; main.cu:131-210) through the C++
+    overloads of include/cbet_reference_api.hpp must give the golden text of `make test` (Makefile:14-17)."""
+    import subprocess
+    from cbet_raytracing_3d_amd import build
+    from conftest import ROOT
+    exe = build.REF_SHAPED_PATH
+    assert os.path.exists(exe), "cbet-ref-shaped not built"
+    out = subprocess.run([exe, "--n", "100", "--print"], cwd=ROOT, capture_output=True, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()
+    assert len(out.stdout) == 12544620
+    assert hashlib.md5(out.stdout).hexdigest() == "cc0909ed1c5938704c51165dc20cb829"
+    bad = subprocess.run([exe, "--n", "64", "--gpus", "2"], cwd=ROOT, capture_output=True, timeout=300, text=True)
+    assert bad.returncode != 0 and "hipSetDevice(1)" in bad.stdout       # one-GPU box: the helper prints the reason to cout (multi_gpu.cpp:9-27), the driver stops
