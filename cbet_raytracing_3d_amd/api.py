@@ -114,7 +114,7 @@ EXPORTS = [
     "cbet_write_text", "cbet_edep_average", "cbet_edep_average_device", "cbet_node_coordinates", "cbet_write_npy",
     "cbet_debug_bounds_violations",
     "cbet_gain_params_default", "cbet_gain_constants", "cbet_trace_cbet", "cbet_gain_field",
-    "cbet_cbet_workspace_bytes", "cbet_cbet_solve",
+    "cbet_cbet_workspace_bytes", "cbet_cbet_solve", "cbet_gain_field_slab",
 ]
 
 _lib = None
@@ -174,6 +174,7 @@ def lib():
     L.cbet_trace_cbet.argtypes = [C.c_int, C.c_uint, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp,
                                   C.c_double, C.c_double, C.c_double, C.POINTER(Params), C.POINTER(GainParams), vp, vp]
     L.cbet_gain_field.argtypes = [vp, vp, vp, vp, vp, C.POINTER(Params), C.POINTER(GainParams), vp, vp]
+    L.cbet_gain_field_slab.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.POINTER(Params), C.POINTER(GainParams), vp, vp]
     L.cbet_cbet_workspace_bytes.argtypes = [C.POINTER(Params)]
     L.cbet_cbet_workspace_bytes.restype = C.c_size_t
     L.cbet_cbet_solve.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(Params), C.POINTER(GainParams), vp, vp, vp,
@@ -400,6 +401,11 @@ def trace_cbet(b, nindices, ne3d, kappa3d, gain, quantity, out, beam_gain, bbeam
 def gain_field(fields, ne3d, gain, scratch, change, params, gain_params, ctx, stream=None):
     _check(lib().cbet_gain_field(_addr(fields), _addr(ne3d), _addr(gain), _addr(scratch), _addr(change),
                                  C.byref(params), C.byref(gain_params), ctx.handle, _addr(stream)))
+
+
+def gain_field_slab(fields, ne3d, gain, scratch, change, hx_lo, hx_hi, params, gain_params, ctx, stream=None):
+    _check(lib().cbet_gain_field_slab(_addr(fields), _addr(ne3d), _addr(gain), _addr(scratch), _addr(change), hx_lo, hx_hi,
+                                      C.byref(params), C.byref(gain_params), ctx.handle, _addr(stream)))
 
 
 def cbet_workspace_bytes(params):

@@ -733,11 +733,19 @@ int cbet_trace_cbet(int b, unsigned nindices, const double *ne3d, const double *
 int cbet_gain_field(double *fields, const double *ne3d, double *gain, double *scratch, double *change,
                     const cbet_params *p, const cbet_gain_params *g, cbet_context *ctx, void *stream)
 {
+    return cbet_gain_field_slab(fields, ne3d, gain, scratch, change, 0, p ? p->nx + 2 : 0, p, g, ctx, stream);
+}
+
+int cbet_gain_field_slab(double *fields, const double *ne3d, double *gain, double *scratch, double *change,
+                         int hx_lo, int hx_hi, const cbet_params *p, const cbet_gain_params *g,
+                         cbet_context *ctx, void *stream)
+{
     if (!ctx) return fail(CBET_EINVAL, "NULL context");
     if (int rc = validate(p)) return rc;
     if (int rc = check_geometry(ctx, p)) return rc;
     if (int rc = validate_gain(p, g)) return rc;
     if (!fields || !gain) return fail(CBET_EINVAL, "NULL device pointer");
+    if (hx_lo < 0 || hx_hi > p->nx + 2 || hx_hi < hx_lo) return fail(CBET_EINVAL, "slab [%d,%d) outside the haloed grid [0,%d)", hx_lo, hx_hi, p->nx + 2);
     double cs = 0, gc = 0;
     if (int rc = cbet_gain_constants(p, g, nullptr, &cs, &gc)) return rc;
     const cbet_derived &d = ctx->d;
@@ -750,6 +758,7 @@ int cbet_gain_field(double *fields, const double *ne3d, double *gain, double *sc
     a.mach_r0 = g->mach_r0; a.mach_0 = g->mach_0; a.mach_r1 = g->mach_r1; a.mach_1 = g->mach_1;
     a.relax = g->relax;
     a.fields = fields; a.ne3d = ne3d ? ne3d : ctx->ne3d; a.gain = gain; a.scratch = scratch; a.change = change;
+    a.hx_lo = hx_lo; a.hx_hi = hx_hi;
     DeviceGuard guard;
     CBET_HIP(hipSetDevice(ctx->gpu));
     CBET_HIP(launch_gain_field(a, (hipStream_t)stream));

@@ -92,6 +92,7 @@ struct GainArgs {
     double *gain;                           // [nbeams][hsize]
     double *scratch;                        // [nbeams][hsize] work array of the symmetric kernel, or NULL (ordered kernel)
     double *change;                         // device {sum |new-old|, sum |new|} accumulators, or NULL
+    int hx_lo, hx_hi;                       // planes [hx_lo, hx_hi) of the haloed grid to update (a rank's slab; 0 .. nx+2 = all)
 };
 
 hipError_t launch_tabulate(const TabulateArgs &a, hipStream_t stream);

@@ -54,10 +54,11 @@ __device__ __forceinline__ CellState cell_state(const GainArgs &a, long h)
 //            stored only where it changes.
 __global__ void __launch_bounds__(256) k_gain_field(const GainArgs a)
 {
-    const int HX = a.nx + 2, HY = a.ny + 2, HZ = a.nz + 2;
-    const long hsize = (long)HX * HY * HZ;
+    const int HY = a.ny + 2, HZ = a.nz + 2;
+    const long hsize = (long)(a.nx + 2) * HY * HZ;
     const long total = hsize * a.nbeams;
-    const int bx = (HX + 1) / 2, by = (HY + 3) / 4, bz = (HZ + 7) / 8;
+    const int bx0 = a.hx_lo >> 1, bx = ((a.hx_hi + 1) >> 1) - bx0;   // brick columns touching the slab [hx_lo, hx_hi)
+    const int by = (HY + 3) / 4, bz = (HZ + 7) / 8;
     const long bricks = (long)bx * by * bz;
     const int lane = threadIdx.x & (kWave - 1);
     const long wave0 = (long)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
@@ -67,9 +68,9 @@ __global__ void __launch_bounds__(256) k_gain_field(const GainArgs a)
     for (long brick = wave0; brick < bricks; brick += nwaves) {
         const int ibz = (int)(brick % bz);
         const long t = brick / bz;
-        const int iby = (int)(t % by), ibx = (int)(t / by);
+        const int iby = (int)(t % by), ibx = bx0 + (int)(t / by);
         const int hi = 2 * ibx + (lane >> 5), hj = 4 * iby + ((lane >> 3) & 3), hk = 8 * ibz + (lane & 7);
-        const bool valid = hi < HX && hj < HY && hk < HZ;
+        const bool valid = hi >= a.hx_lo && hi < a.hx_hi && hj < HY && hk < HZ;
         const long h = valid ? ((long)hi * HY + hj) * HZ + hk : 0;
         double *fI = a.fields + h, *fx = fI + total, *fy = fx + total, *fz = fy + total;
         const CellState c = cell_state(a, h);
@@ -170,10 +171,11 @@ __device__ __forceinline__ double pair_gain(const BeamAtCell &bi, const BeamAtCe
 
 __global__ void __launch_bounds__(256) k_gain_field_sym(const GainArgs a)
 {
-    const int HX = a.nx + 2, HY = a.ny + 2, HZ = a.nz + 2;
-    const long hsize = (long)HX * HY * HZ;
+    const int HY = a.ny + 2, HZ = a.nz + 2;
+    const long hsize = (long)(a.nx + 2) * HY * HZ;
     const long total = hsize * a.nbeams;
-    const int bx = (HX + 1) / 2, by = (HY + 3) / 4, bz = (HZ + 7) / 8;
+    const int bx0 = a.hx_lo >> 1, bx = ((a.hx_hi + 1) >> 1) - bx0;   // brick columns touching the slab [hx_lo, hx_hi)
+    const int by = (HY + 3) / 4, bz = (HZ + 7) / 8;
     const long bricks = (long)bx * by * bz;
     const int lane = threadIdx.x & (kWave - 1);
     const long wave0 = (long)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
@@ -183,9 +185,9 @@ __global__ void __launch_bounds__(256) k_gain_field_sym(const GainArgs a)
     for (long brick = wave0; brick < bricks; brick += nwaves) {
         const int ibz = (int)(brick % bz);
         const long t = brick / bz;
-        const int iby = (int)(t % by), ibx = (int)(t / by);
+        const int iby = (int)(t % by), ibx = bx0 + (int)(t / by);
         const int hi = 2 * ibx + (lane >> 5), hj = 4 * iby + ((lane >> 3) & 3), hk = 8 * ibz + (lane & 7);
-        const bool valid = hi < HX && hj < HY && hk < HZ;
+        const bool valid = hi >= a.hx_lo && hi < a.hx_hi && hj < HY && hk < HZ;
         const long h = valid ? ((long)hi * HY + hj) * HZ + hk : 0;
         double *fI = a.fields + h, *fx = fI + total, *fy = fx + total, *fz = fy + total;
         double *raw = a.scratch + h;
@@ -359,7 +361,8 @@ hipError_t launch_edep_average(const double *edep, double *out, int nx, int ny, 
 
 hipError_t launch_gain_field(const GainArgs &a, hipStream_t stream)
 {
-    const long bricks = (long)((a.nx + 3) / 2) * ((a.ny + 5) / 4) * ((a.nz + 9) / 8);  // 2 x 4 x 8 cells of the haloed grid each
+    if (a.hx_hi <= a.hx_lo) return hipSuccess;
+    const long bricks = (long)(((a.hx_hi + 1) >> 1) - (a.hx_lo >> 1)) * ((a.ny + 5) / 4) * ((a.nz + 9) / 8);  // 2 x 4 x 8 cells of the haloed grid each
     long blocks = (bricks + 3) / 4;                                                    // four wavefronts per workgroup
     if (blocks > 256 * 64) blocks = 256 * 64;
     if (a.scratch) hipLaunchKernelGGL(k_gain_field_sym, dim3((unsigned)blocks), dim3(256), 0, stream, a);

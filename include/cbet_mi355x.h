@@ -338,6 +338,14 @@ int cbet_trace_cbet(int b, unsigned nindices, const double *ne3d, const double *
  */
 int cbet_gain_field(double *fields, const double *ne3d, double *gain, double *scratch, double *change,
                     const cbet_params *p, const cbet_gain_params *g, cbet_context *ctx, void *stream);
+/*
+ * The same for the x-planes [hx_lo, hx_hi) of the deposit grid only (0 <= hx_lo <= hx_hi <= nx+2): one rank's
+ * slab when the gain update is shared between ranks (tracer.cbet_fixed_point_slabs).  The arrays keep their full
+ * shape; cells outside the slab are neither read for the update nor written.
+ */
+int cbet_gain_field_slab(double *fields, const double *ne3d, double *gain, double *scratch, double *change,
+                         int hx_lo, int hx_hi, const cbet_params *p, const cbet_gain_params *g,
+                         cbet_context *ctx, void *stream);
 /* Bytes of device workspace cbet_cbet_solve needs: 6 nbeams (n+2)^3 doubles + a few scalars. */
 size_t cbet_cbet_workspace_bytes(const cbet_params *p);
 /*

@@ -228,3 +228,42 @@ def test_cbet_wide_index_path(api, inputs, setup, torch_cuda):
     tr.launch_cbet(e, gp, gain=gain)
     assert parity_err(ew.cpu().numpy(), e.cpu().numpy()) < TOL
     trw.close()
+
+
+def test_gain_update_by_slabs_equals_the_whole(api, setup, torch_cuda):
+    """cbet_gain_field_slab: updating the x-slabs one after the other (ragged split, odd boundaries that cut through
+    the kernel's two-plane bricks) gives bit for bit the gain of one update over the whole grid, and the
+    convergence sums add up; cells outside a slab are not touched."""
+    tr, gp = setup["tr"], setup["gp"]
+    whole = tr.new_grid(per_beam=True)
+    ch_whole = torch_cuda.zeros(2, dtype=torch_cuda.float64, device="cuda")
+    tr.gain_field(torch_cuda.from_numpy(setup["ofields"].copy()).cuda(), whole, gp, ch_whole,
+                  scratch=torch_cuda.empty_like(whole))
+    for sym in (False, True):
+        parts = tr.new_grid(per_beam=True).fill_(-7.0)
+        ref = tr.new_grid(per_beam=True).fill_(-7.0)
+        tr.gain_field(torch_cuda.from_numpy(setup["ofields"].copy()).cuda(), ref, gp, None,
+                      scratch=torch_cuda.empty_like(ref) if sym else None)
+        ch = torch_cuda.zeros(2, dtype=torch_cuda.float64, device="cuda")
+        fields = torch_cuda.from_numpy(setup["ofields"].copy()).cuda()
+        cuts = [0, 1, 12, 13, 29, N + 2]
+        for x0, x1 in zip(cuts[:-1], cuts[1:]):
+            before = parts.clone()
+            tr.gain_field(fields, parts, gp, ch, scratch=torch_cuda.empty_like(parts) if sym else None, x_lo=x0, x_hi=x1)
+            assert torch_cuda.equal(parts[:, :x0], before[:, :x0]) and torch_cuda.equal(parts[:, x1:], before[:, x1:])
+        assert torch_cuda.equal(parts, ref)
+    with pytest.raises(api.CbetError):
+        tr.gain_field(fields, parts, gp, None, x_lo=5, x_hi=N + 3)
+
+
+def test_slab_owned_loop_on_one_rank_equals_the_plain_loop(api, setup, torch_cuda):
+    """RayTracer.cbet_solve(slabs=True) with world_size 1 (its exchanges are no-ops) must reproduce the plain loop;
+    the multi-rank exchanges themselves are covered over gloo in tests/test_cbet_model.py."""
+    tr = setup["tr"]
+    gp = api.default_gain_params(tolerance=1e-6, max_passes=12, relax=1.0)
+    e1, e2 = tr.new_grid(), tr.new_grid()
+    r1 = tr.cbet_solve(e1, gp)
+    r2 = tr.cbet_solve(e2, gp, slabs=True)
+    assert r1["converged"] and r2["converged"] and r1["passes"] == r2["passes"]
+    assert parity_err(e2.cpu().numpy(), e1.cpu().numpy()) < 1e-9
+    assert np.abs(r1["beam_gain"] - r2["beam_gain"]).max() < 1e-9 * np.abs(r1["beam_gain"]).max()
