@@ -54,6 +54,11 @@ static int validate(const cbet_params *p)
     if (p->nx < 3 || p->ny < 3 || p->nz < 3) return fail(CBET_EINVAL, "grid needs >= 3 nodes per axis");
     if ((long)(p->nx + 2) * (p->ny + 2) * (p->nz + 2) >= 0x7FFFFFFFL)
         return fail(CBET_EINVAL, "grid too large for 32-bit node tags ((n+2)^3 must be < 2^31)");
+    // the kernels build cell and haloed-node indices with 24-bit multiplies (v_mul_i32_i24): both operands of
+    // (ci*ny + cj)*nz + ck and of X*(ny+2)(nz+2) + Y*(nz+2) + Z must stay below 2^23 (thin anisotropic grids)
+    if ((long)p->nx * p->ny >= (1L << 23) || (long)(p->ny + 2) * (p->nz + 2) >= (1L << 23) || p->nx + 2 >= (1 << 23) ||
+        p->nz + 2 >= (1 << 23))
+        return fail(CBET_EINVAL, "grid too anisotropic for 24-bit index products (need nx*ny < 2^23 and (ny+2)(nz+2) < 2^23)");
     if (!(p->xmax > p->xmin) || !(p->ymax > p->ymin) || !(p->zmax > p->zmin))
         return fail(CBET_EINVAL, "empty extent");
     if (p->nbeams < 1) return fail(CBET_EINVAL, "nbeams < 1");
@@ -520,7 +525,10 @@ static int trace_impl(int b, unsigned nindices, const double *ne3d, const double
         return fail(CBET_EINVAL, "nindices=%u but def.cuh:129 gives %d for these parameters", nindices, ctx->d.nindices);
 
     int beam_lo = p->beam_lo, beam_hi = p->beam_hi;
-    if (beam_hi <= beam_lo) {  // launch_ray_XZ.cu:123 with grid.x = nbeams/nGPUs (main.cu:161)
+    if (beam_hi < beam_lo) return fail(CBET_EINVAL, "beam range [%d,%d) is reversed", beam_lo, beam_hi);
+    // "unset" is beam_lo == beam_hi == 0 only; any other empty range [k,k) is an explicit no-op (a rank that
+    // owns no beam), handled below
+    if (beam_lo == 0 && beam_hi == 0) {  // launch_ray_XZ.cu:123 with grid.x = nbeams/nGPUs (main.cu:161)
         const int ng = p->ngpus > 0 ? p->ngpus : 1;
         const int per = p->nbeams / ng;
         beam_lo = b * per;

@@ -267,3 +267,42 @@ def test_slab_owned_loop_on_one_rank_equals_the_plain_loop(api, setup, torch_cud
     assert r1["converged"] and r2["converged"] and r1["passes"] == r2["passes"]
     assert parity_err(e2.cpu().numpy(), e1.cpu().numpy()) < 1e-9
     assert np.abs(r1["beam_gain"] - r2["beam_gain"]).max() < 1e-9 * np.abs(r1["beam_gain"]).max()
+
+
+def test_config3_cbet_solve_256_properties(api, inputs, torch_cuda):
+    """BASELINE config 3's "full CBET gain iteration": 256^3, 60 beams, the native fixed-point loop with the
+    default gain parameters (the run bench.py reports in its `cbet` object).  Parity unpinned (no reference CBET
+    code), so the properties: hooks off = the plain pass at this size; the iteration converges inside
+    max_passes; what the beams gain and lose cancels (imbalance < 5e-3 at tolerance 1e-4); every pass traces
+    every ray; CBET lowers the absorbed total (energy leaves with the outgoing light)."""
+    from cbet_raytracing_3d_amd.tracer import RayTracer
+    bn, r, ne, te = inputs
+    tr = RayTracer(api.default_params(256), r, ne, te, beam_norm=bn)
+    gp = api.default_gain_params()
+    plain = tr.new_grid()
+    tr.counters(reset=True)
+    tr.launch(plain)
+    c_plain = tr.counters(reset=True)
+    assert c_plain.ray_steps == 2123497670
+    off = tr.new_grid()
+    bg = torch_cuda.zeros(60, dtype=torch_cuda.float64, device="cuda")
+    tr.launch_cbet(off, gp, gain=None, beam_gain=bg)          # hooks compiled in, no gain field
+    assert tr.counters(reset=True).ray_steps == c_plain.ray_steps
+    assert float(bg.abs().sum()) == 0.0
+    assert parity_err(off.cpu().numpy(), plain.cpu().numpy()) < TOL
+    plain_sum = float(plain.sum())
+    del off
+    ws = torch_cuda.empty(api.cbet_workspace_bytes(tr.params) // 8, dtype=torch_cuda.float64, device="cuda")
+    e = tr.new_grid()
+    rep = api.cbet_solve(tr.d_te, tr.d_r, tr.d_ne, e, tr.d_bbeam_norm, tr.d_beam_norm, tr.d_pow_r, tr.d_phase_r,
+                         tr.params, gp, workspace=ws, ctx=tr.ctx, stream=torch_cuda.cuda.current_stream().cuda_stream)
+    torch_cuda.cuda.synchronize()
+    assert rep.converged == 1 and 2 <= rep.passes <= gp.max_passes
+    assert rep.change < gp.tolerance
+    assert rep.imbalance < 5e-3
+    assert rep.ray_steps_final > 0 and rep.ray_steps > rep.passes * 1.5e9
+    ratio = float(e.sum()) / plain_sum
+    assert 0.3 < ratio < 0.95                                   # DESIGN.md 9: ~41 % less absorbed with the defaults
+    print("256^3 CBET solve: %d passes, change %.2e, imbalance %.2e, absorbed/plain %.3f" %
+          (rep.passes, rep.change, rep.imbalance, ratio))
+    tr.close()
