@@ -96,12 +96,6 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n", type=int, default=256, help="grid nodes per axis (BASELINE config 3: 256)")
     ap.add_argument("--variant", type=int, default=0, help="cbet_params.kernel_variant (0 = default)")
-    ap.add_argument("--window", type=int, default=0, help="cbet_params.lds_window_log2 (0 = default)")
-    ap.add_argument("--copies", type=int, default=-1, help="cbet_params.lds_copies_log2 (-1 = default)")
-    ap.add_argument("--pre", type=int, default=-1, help="cbet_params.lds_prereduce (-1 = default)")
-    ap.add_argument("--flip", type=int, default=-1, help="cbet_params.lds_corner_flip (-1 = default)")
-    ap.add_argument("--twobox", type=int, default=-1, help="cbet_params.lds_two_boxes (-1 = default)")
-    ap.add_argument("--xcd", type=int, default=-1, help="cbet_params.xcd_order (-1 = default)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank flow on a 1-GPU box together with CBET_BENCH_DEVICE)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -132,9 +126,7 @@ def main():
     n = args.n
     r, ne, te = api.load_s83177()
     bn = api.omega60_beam_norm()
-    p = api.default_params(n, kernel_variant=args.variant, lds_window_log2=args.window,
-                           lds_copies_log2=args.copies, lds_prereduce=args.pre,
-                           lds_corner_flip=args.flip, lds_two_boxes=args.twobox, xcd_order=args.xcd)
+    p = api.default_params(n, kernel_variant=args.variant)
     tr = RayTracer(p, r, ne, te, beam_norm=bn)
     edep = tr.new_grid()
     si, sc = shard_of_rank(rank, world)

@@ -44,11 +44,8 @@ class Params(C.Structure):
         ("ngpus", C.c_int),
         ("beam_lo", C.c_int), ("beam_hi", C.c_int),
         ("shard_index", C.c_int), ("shard_count", C.c_int),
-        ("kernel_variant", C.c_int), ("lds_window_log2", C.c_int), ("lds_copies_log2", C.c_int),
-        ("lds_prereduce", C.c_int), ("lds_corner_flip", C.c_int),
-        ("lds_two_boxes", C.c_int), ("force_wide_index", C.c_int), ("xcd_order", C.c_int),
+        ("kernel_variant", C.c_int), ("force_wide_index", C.c_int),
         ("per_beam_grids", C.c_int), ("patch_order", C.c_int),
-        ("order_phases", C.c_int),
     ]
 
     def copy(self, **overrides):
@@ -245,18 +242,8 @@ def shard_items(p, nbeams_local, shard_index, shard_count):
     live = live_ray_list(p)
     bpb = (len(live) + 63) // 64
     beams, ids = [], []
-    phases = 1
-    if p.patch_order != 0:          # see cbet_params.order_phases
-        phases = 1 if p.order_phases < 1 else p.order_phases
-    phases = max(1, min(phases, bpb))
-    plen = (bpb + phases - 1) // phases
-    while phases > 1 and (phases - 1) * plen >= bpb:
-        phases -= 1
     for g in range(shard_index, nbeams_local * bpb, max(1, shard_count)):
-        ph = min(phases - 1, g // (nbeams_local * plen))
-        rem = g - ph * nbeams_local * plen
-        ln = plen if ph < phases - 1 else bpb - (phases - 1) * plen
-        b, k = rem // ln, ph * plen + rem % ln
+        b, k = g // bpb, g % bpb
         chunk = live[64 * k: 64 * k + 64]
         chunk = chunk[chunk >= 0]
         beams.append(np.full(len(chunk), b, dtype=np.int32))

@@ -13,8 +13,8 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libcbet_mi355x.so")
-SOURCES = ["cbet_kernels.hip", "cbet_grid_kernels.hip", "cbet_abi.cpp", "cbet_host.cpp", "cbet_output.cpp"]
-HEADERS = [os.path.join(CSRC, "cbet_device.h"), os.path.join(CSRC, "cbet_relocate.h"), os.path.join(ROOT, "include", "cbet_mi355x.h"),
+SOURCES = ["cbet_kernels.hip", "cbet_trace_window.hip", "cbet_grid_kernels.hip", "cbet_abi.cpp", "cbet_host.cpp", "cbet_output.cpp"]
+HEADERS = [os.path.join(CSRC, "cbet_device.h"), os.path.join(CSRC, "cbet_relocate.h"), os.path.join(CSRC, "cbet_trace_common.h"), os.path.join(ROOT, "include", "cbet_mi355x.h"),
            os.path.join(ROOT, "include", "cbet_omega_beams.h")]
 
 # -ffp-contract=off: a ray's fp64 arithmetic must be the reference's operation sequence (no fused

@@ -234,13 +234,7 @@ int cbet_params_default(cbet_params *p, int n)
     p->shard_index = 0;
     p->shard_count = 1;
     p->kernel_variant = CBET_KERNEL_DEFAULT;
-    p->lds_copies_log2 = -1;
-    p->lds_prereduce = -1;
-    p->lds_corner_flip = -1;
-    p->lds_two_boxes = -1;
-    p->xcd_order = -1;
     p->patch_order = 1;
-    p->order_phases = -1;
     return CBET_OK;
 }
 
@@ -543,22 +537,9 @@ static int trace_impl(int b, unsigned nindices, const double *ne3d, const double
     if (variant != CBET_KERNEL_GLOBAL_ATOMICS && variant != CBET_KERNEL_LDS_COMBINE &&
         variant != CBET_KERNEL_LDS_WINDOW)
         return fail(CBET_EINVAL, "unknown kernel_variant %d", p->kernel_variant);
-    int wl = p->lds_window_log2 ? p->lds_window_log2 : 3;
-    if (wl != 3 && wl != 4) return fail(CBET_EINVAL, "lds_window_log2 must be 3 or 4");
-    // LDS_WINDOW tuning knobs; "auto" (-1) = the measured best: two boxes of one tile each,
-    // lane-dependent corner order, no privatised copies, no lane pre-reduction
-    const bool two_auto = p->lds_two_boxes < 0 && p->lds_copies_log2 <= 0 && p->lds_prereduce <= 0 &&
-                          p->lds_corner_flip != 0 && wl == 3;
-    const bool two = p->lds_two_boxes > 0 || two_auto;
-    int rl = p->lds_copies_log2 < 0 ? 0 : p->lds_copies_log2;
-    if (rl > 2) return fail(CBET_EINVAL, "lds_copies_log2 must be -1 (auto) or 0..2");
-    int pre = p->lds_prereduce < 0 ? 0 : p->lds_prereduce;
-    if (pre > 2) return fail(CBET_EINVAL, "lds_prereduce must be -1 (auto) or 0..2");
-    if (two && (rl != 0 || pre != 0 || wl != 3 || p->lds_corner_flip == 0))
-        return fail(CBET_EINVAL, "lds_two_boxes needs lds_window_log2=3, one copy, no pre-reduction, corner flip on");
     const bool cbet_hooks = hooks.gain || hooks.quantity != 0 || hooks.beam_gain;
-    if (cbet_hooks && !(variant == CBET_KERNEL_LDS_WINDOW && wl == 3 && rl == 0 && pre == 0 && p->lds_corner_flip != 0))
-        return fail(CBET_EINVAL, "the CBET hooks exist for the default kernel configuration (and lds_two_boxes = 0) only");
+    if (cbet_hooks && variant != CBET_KERNEL_LDS_WINDOW)
+        return fail(CBET_EINVAL, "the CBET hooks exist for the default kernel (CBET_KERNEL_LDS_WINDOW) only");
 
     const cbet_derived &d = ctx->d;
     TraceArgs a{};
@@ -581,15 +562,6 @@ static int trace_impl(int b, unsigned nindices, const double *ne3d, const double
     a.total_bundles = (long)a.nbeams_local * a.bundles_per_beam;
     a.shard_index = p->shard_count > 1 ? p->shard_index : 0;
     a.shard_count = p->shard_count > 1 ? p->shard_count : 1;
-    // work-item order (cbet_params.order_phases; auto: 1 = plain beam-major, the fastest measured)
-    {
-        int phases = p->patch_order != 0 ? (p->order_phases < 1 ? 1 : p->order_phases) : 1;
-        if (phases > a.bundles_per_beam) phases = a.bundles_per_beam;
-        a.phase_len = (a.bundles_per_beam + phases - 1) / phases;
-        while (phases > 1 && (phases - 1) * a.phase_len >= a.bundles_per_beam) --phases;  // last phase non-empty
-        a.phases = phases;
-    }
-    a.xcd_chunk = p->xcd_order > 0 ? 1 : 0;  // launch_trace turns the flag into the chunk length
     a.ne3d = ne3d ? ne3d : ctx->ne3d;
     a.kap3d = kappa3d ? kappa3d : ctx->kap3d;
     a.beam_norm = beam_norm; a.bbeam_norm = bbeam_norm; a.pow_r = pow_r; a.phase_r = phase_r;
@@ -599,18 +571,9 @@ static int trace_impl(int b, unsigned nindices, const double *ne3d, const double
     a.counters = ctx->counters;
     a.gain = hooks.gain; a.hsize = d.edep_size; a.quantity = hooks.quantity;
     a.max_exponent = hooks.max_exponent; a.beam_gain = hooks.beam_gain;
-    a.timeline = nullptr;
-#ifdef CBET_EXPERIMENT_TIMELINE
-    {   // diagnostic builds: the caller passes a device buffer of 3 x workgroups u64 through the environment
-        const char *env = std::getenv("CBET_TIMELINE_PTR");
-        if (env) a.timeline = (unsigned long long *)std::strtoull(env, nullptr, 0);
-    }
-#endif
-
     DeviceGuard guard;
     CBET_HIP(hipSetDevice(ctx->gpu));
-    const bool flip = p->lds_corner_flip != 0;  // auto: on
-    CBET_HIP(launch_trace(a, variant, wl, rl, pre, flip, two, p->force_wide_index != 0, (hipStream_t)stream));
+    CBET_HIP(launch_trace(a, variant, p->force_wide_index != 0, (hipStream_t)stream));
     return CBET_OK;
 }
 

@@ -61,15 +61,16 @@ struct TraceArgs {
     int beam_lo, nbeams_local, bundles_per_beam;
     long total_bundles;
     int shard_index, shard_count;
-    int phases, phase_len;                  // work-item order: see k_trace (phases >= 1, phase_len = patches per phase)
-    int xcd_chunk;                          // > 0: XCD-aware workgroup -> work-item map (see k_trace)
     // tables
     const double *ne3d, *kap3d;
     const double *beam_norm, *bbeam_norm, *pow_r, *phase_r;
     double *edep;
     long grid_stride;                       // 0: one grid for all beams; else doubles between per-beam grids
     unsigned long long *counters;
-    unsigned long long *timeline;           // diagnostic builds only: 3 words per workgroup, else NULL
+    // bounds-audit builds (-DCBET_DEBUG_BOUNDS) only; unused otherwise
+    unsigned long long *audit_count;        // violations counter
+    const double *audit_lo, *audit_hi;      // the grid range a launch may add into
+    unsigned long long audit_nodes, audit_hsize;  // entries of a node table / of a beam's haloed gain grid
     // CBET extension (no reference counterpart).  All zero / NULL = the reference path.
     const double *gain;                     // [nbeams][(n+2)^3] gain coefficient on the deposit grid, 1/cm
     long hsize;                             // (nx+2)(ny+2)(nz+2)
@@ -97,8 +98,9 @@ struct GainArgs {
 
 hipError_t launch_tabulate(const TabulateArgs &a, hipStream_t stream);
 hipError_t audit_violations(unsigned long long *out, bool reset, hipStream_t stream);
-hipError_t launch_trace(const TraceArgs &a, int variant, int window_log2, int copies_log2, int prereduce,
-                        bool corner_flip, bool two_boxes, bool force_idx64, hipStream_t stream);
+// variant: CBET_KERNEL_GLOBAL_ATOMICS, _LDS_COMBINE (cbet_kernels.hip) or _LDS_WINDOW (cbet_trace_window.hip)
+hipError_t launch_trace(const TraceArgs &a, int variant, bool force_idx64, hipStream_t stream);
+hipError_t launch_trace_window(const TraceArgs &a, bool force_idx64, hipStream_t stream);
 hipError_t launch_gain_field(const GainArgs &a, hipStream_t stream);
 hipError_t launch_edep_average(const double *edep, double *out, int nx, int ny, int nz, hipStream_t stream);
 

@@ -47,21 +47,23 @@ CBET_HD int relocate_closed(int c, double f, int n)
     return up ? upper : lower;
 }
 
-// Fast evaluation for an INTERIOR cell (1 <= c <= n-2, so neither neighbour needs a bound check):
-// only c+1 and c-1 are examined.  `ambiguous` is raised when the match lies within 2e-4 of the far
-// edge of its +-0.5001 band -- the only situation in which a second candidate (c for an upward
-// match, c-2 for a downward one) can match as well and relocate_closed() could differ.  The
-// margin (0.4998 vs the 0.4999 where the bands start to overlap) is 1e-4, ten orders above the
-// rounding of the subtractions.  Callers fall back to relocate_closed() when any lane is ambiguous
-// or sits on a face cell.
-CBET_HD int relocate_fast_interior(int c, double f, bool &ambiguous)
+// Exact evaluation for a DEEP INTERIOR cell, kRelocateDeep <= c <= n-3, given fc = (double)c.
+// For such cells all four candidates c+1, c, c-1, c-2 exist, and every difference the reference forms,
+// (double)q - f for q in {c-2 .. c+1} with |f - c| < 1.5, is exact (Sterbenz: q/2 <= f <= 2q once q >= 4),
+// as is g = f - fc.  The loop above is then a function of the real number g alone:
+//   up = 1-T < g < 1+T,  mid = |g| < T,  dn1 = -1-T < g < -1+T,  dn2 = -2-T < g < -2+T      (T = 0.5001)
+//   up ? (mid ? c : c+1) : (dn1 ? (dn2 ? c-2 : c-1) : c)
+// and for |g| < 1.4998 (so neither dn2 nor the "jumped more than a cell" case g >= 1+T can occur):
+//   c+1 iff g >= T;   c-1 iff g < T-1;   c otherwise                (T - 1.0 is exact in fp64)
+// -- two comparisons instead of eight, no ambiguity band.  `far` is raised when |g| >= 1.4998 (a ray
+// that moved more than a cell: impossible at Courant 0.5, but then the caller must use relocate_closed).
+constexpr int kRelocateDeep = 6;
+CBET_HD int relocate_deep_interior(int c, double fc, double f, bool &far)
 {
-    const double half = 0.5001, safe = 0.4998;
-    const double fc = (double)c;
-    const double au = fabs((fc + 1.0) - f), ad = fabs((fc - 1.0) - f);
-    const bool up = au < half, dn = ad < half;
-    ambiguous = ambiguous || (up && au > safe) || (dn && ad > safe);
-    return up ? c + 1 : (dn ? c - 1 : c);
+    const double half = 0.5001;
+    const double g = f - fc;
+    far = far || !(fabs(g) < 1.4998);
+    return c + ((g >= half) ? 1 : 0) - ((g < (half - 1.0)) ? 1 : 0);
 }
 
 }  // namespace cbet

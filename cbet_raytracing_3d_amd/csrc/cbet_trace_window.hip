@@ -1,0 +1,713 @@
+// cbet_trace_window.hip -- the shipped ray integrator for gfx950 (CDNA4): CBET_KERNEL_LDS_WINDOW.
+//
+// One wavefront (64 lanes, one workgroup) = one ray bundle = one 8x8-ray patch of a beam's cross
+// section.  A ray's arithmetic is the reference's, operation for operation
+// (/root/reference/launch_ray_XZ.cu:207-357; the file is built with -ffp-contract=off); what is
+// MI355X-specific is everything around it:
+//
+//   * plasma: node tables ne3d / kappa3d in HBM (k_tabulate), gathered by 32-bit byte offsets from a
+//     uniform base; the seven gathers of a step are issued as soon as the ray's new cell is known and
+//     are consumed one step later (software pipeline).
+//   * relocation: for cells deep inside the grid the reference's mutating-bound candidate loop
+//     (:282-292) is a function of g = f - cell alone and every difference it forms is exact, so it is
+//     evaluated with two comparisons (cbet_relocate.h, relocate_deep_interior; fuzzed against the
+//     literal loop on the CPU).  Whether a wave is "deep inside" is decided on the SCALAR unit from the
+//     deposit windows' origins; near the faces the wave takes the closed form with the face rules.
+//   * deposit: wave-private dense LDS tiles of fp64 accumulators ("boxes") whose origins follow the
+//     bundle.  A lane whose eight target nodes lie in its box issues eight ds_add_f64; the plane (or,
+//     along z, the 64-byte-aligned brick of 8 planes) that leaves a box when its origin moves is
+//     written back with global fp64 atomics -- z-bricks make every such atomic request a full 64-B
+//     line (the memory-side atomic path is priced per 64-B request, MI355X_MICROARCH.md "Global float
+//     atomics").  A second box adopts lanes that leave the first (bundles fan out after the turning
+//     point).  Corner order is lane-dependent so that rays sharing all 8 nodes hit different LDS
+//     addresses in any one ds_add_f64.
+//
+// Template parameters: WZ = z extent of a tile (16: aligned z-bricks; 8: single z-planes, used by the
+// CBET field pass whose three extra component tiles would not fit otherwise); GENERIC = run-time
+// absorption flag and 64-bit table indexing (grids of >= 2^32 table bytes, bookkeeping mode) instead
+// of the compiled-in common case; CBET = 0 none, 1 gain hooks, 4 fused four-component field pass
+// (no reference counterpart: DESIGN.md section 9).
+#include <hip/hip_runtime.h>
+
+#include "cbet_trace_common.h"
+
+namespace cbet {
+namespace {
+
+template <int WZ_>
+struct Tile {
+    static constexpr int W = 8;                 // x and y extent (nodes)
+    static constexpr int WZ = WZ_;              // z extent
+    static constexpr int ZM = WZ - 1;
+    // Padded layout (doubles): ds_add_f64 costs the CU ~8 cycles when the lanes' addresses fall on different
+    // bank pairs, +2 per lane sharing a bank, +3 per lane sharing an address (scripts/ubench/lds_atomic.hip),
+    // and a bundle's footprint is a few nodes wide per axis: rows are padded by one entry, planes by four.
+    static constexpr int YS = WZ + 1;
+    static constexpr int XS = W * YS + 4;
+    static constexpr int N = W * XS;            // doubles per tile
+    static constexpr int S = W - 2;             // largest x / y offset of a lane's low corner inside the box
+    static constexpr int SZ = WZ - 2;           // ... z offset
+    static constexpr bool BRICK = WZ == 16;     // z follows in aligned bricks of 8 planes
+    static constexpr int DT = W * W * WZ;       // unpadded component tile (CBET field pass)
+    static __device__ __forceinline__ int slot_d(int tx, int ty, int tz) { return (tx * W + ty) * WZ + tz; }
+};
+
+// Wave-uniform state of one box: origin = haloed index of its low corner; it covers [o, o+W) x [o, o+W) x [o, o+WZ).
+struct Origin {
+    int x, y, z;
+};
+
+__device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
+// absolute coordinate in [o, o + 8) (or [o, o + WZ)) whose residue is r
+__device__ __forceinline__ int abs8(int o, int r) { return o + ((r - o) & 7); }
+template <int WZ>
+__device__ __forceinline__ int absz(int o, int r) { return o + ((r - o) & (WZ - 1)); }
+
+struct WaveCounters {
+    int n_atomics = 0;        // per lane
+    int n_miss = 0;           // per lane: ray-steps deposited straight to HBM
+    unsigned steps_miss = 0;  // wave-uniform, packed: wave-steps << 16 | wave-steps with a window miss
+    unsigned slabs_bsteps = 0;// wave-uniform, packed: planes / bricks retired << 16 | wave-steps with box B live
+};
+
+// Take the plane `coord` (absolute, inside the box) of axis AX (0: x, 1: y) out of a tile: read the sums, zero
+// the non-zero ones and either hand them back in (dv, dn) -- value and flat haloed node -- so that the caller
+// can issue the global atomic LATER, behind the next step's gathers (loads, stores and atomics share one
+// in-order vmcnt on CDNA: an atomic issued before a load delays that load's data by the atomic's round trip),
+// or (DEFER = false) add them to HBM now.  A plane is 8 x WZ entries: WZ/8 per lane, z fastest across lanes,
+// so one wave instruction covers whole rows -- 64-B lines when the z origin is brick-aligned.
+template <int WZ, int AX, bool DEFER, int NC>
+__device__ __forceinline__ void retire_plane(const TraceArgs &a, double *tile, const Origin &o, int coord, int lane,
+                                             double *edep, int sXh, int sYh, WaveCounters &wc, double (&dv)[2],
+                                             int (&dn)[2], int coff, long gstride)
+{
+    using T = Tile<WZ>;
+    constexpr int IT = T::W * WZ / kWave;
+    const int fixed = coord & 7;
+#pragma unroll
+    for (int e = 0; e < IT; ++e) {
+        const int idx = e * kWave + lane;
+        const int r0 = idx / WZ, r1 = idx & T::ZM;
+        int slot, node, slot_d;
+        const int k = absz<WZ>(o.z, r1);
+        if (AX == 0) {
+            slot = fixed * T::XS + r0 * T::YS + r1;
+            slot_d = T::slot_d(fixed, r0, r1);
+            node = coord * sXh + abs8(o.y, r0) * sYh + k;
+        } else {
+            slot = r0 * T::XS + fixed * T::YS + r1;
+            slot_d = T::slot_d(r0, fixed, r1);
+            node = abs8(o.x, r0) * sXh + coord * sYh + k;
+        }
+        if (!CBET_AUDIT(a, (unsigned)slot < (unsigned)T::N)) continue;
+        const double v = tile[slot];
+        if (NC > 1) {
+#pragma unroll
+            for (int q = 1; q < NC; ++q) {
+                const double vq = tile[coff + (q - 1) * T::DT + slot_d];
+                if (vq != 0.0) {
+                    global_add(a, &edep[q * gstride + node], vq);
+                    tile[coff + (q - 1) * T::DT + slot_d] = 0.0;
+                    ++wc.n_atomics;
+                }
+            }
+        }
+        if (v != 0.0) {  // only nodes that received deposits are non-zero, hence valid
+            tile[slot] = 0.0;
+            ++wc.n_atomics;
+            if (DEFER) {
+                dv[e] = v;
+                dn[e] = node;
+            } else {
+                global_add(a, &edep[node], v);
+            }
+        }
+    }
+}
+
+// z, single planes (WZ = 8): the plane is 8 x 8 (x, y) entries, one per lane, each in its own 64-B line of HBM.
+template <int WZ, bool DEFER, int NC>
+__device__ __forceinline__ void retire_zplane(const TraceArgs &a, double *tile, const Origin &o, int coord, int lane,
+                                              double *edep, int sXh, int sYh, WaveCounters &wc, double &dv, int &dn,
+                                              int coff, long gstride)
+{
+    using T = Tile<WZ>;
+    const int r0 = lane >> 3, r1 = lane & 7, fixed = coord & T::ZM;
+    const int slot = r0 * T::XS + r1 * T::YS + fixed;
+    const int node = abs8(o.x, r0) * sXh + abs8(o.y, r1) * sYh + coord;
+    if (!CBET_AUDIT(a, (unsigned)slot < (unsigned)T::N)) return;
+    const double v = tile[slot];
+    if (NC > 1) {
+        const int slot_d = T::slot_d(r0, r1, fixed);
+#pragma unroll
+        for (int q = 1; q < NC; ++q) {
+            const double vq = tile[coff + (q - 1) * T::DT + slot_d];
+            if (vq != 0.0) {
+                global_add(a, &edep[q * gstride + node], vq);
+                tile[coff + (q - 1) * T::DT + slot_d] = 0.0;
+                ++wc.n_atomics;
+            }
+        }
+    }
+    if (v != 0.0) {
+        tile[slot] = 0.0;
+        ++wc.n_atomics;
+        if (DEFER) {
+            dv = v;
+            dn = node;
+        } else {
+            global_add(a, &edep[node], v);
+        }
+    }
+}
+
+// z, bricks (WZ = 16): the 8 planes [zb, zb + 8), zb a multiple of 8, leave together.  Eight wave instructions,
+// one per tile x index; lanes = (y, z), z fastest: every atomic request is one full 64-B line of HBM.
+template <int WZ>
+__device__ __forceinline__ void retire_zbrick(const TraceArgs &a, double *tile, const Origin &o, int zb, int lane,
+                                              double *edep, int sXh, int sYh, WaveCounters &wc)
+{
+    using T = Tile<WZ>;
+    const int ty = lane >> 3, kz = lane & 7;
+    const int base_slot = ty * T::YS + ((zb + kz) & T::ZM);
+    const int base_node = abs8(o.y, ty) * sYh + zb + kz;
+#pragma unroll
+    for (int tx = 0; tx < T::W; ++tx) {
+        const int slot = tx * T::XS + base_slot;
+        if (!CBET_AUDIT(a, (unsigned)slot < (unsigned)T::N)) continue;
+        const double v = tile[slot];
+        if (v != 0.0) {
+            tile[slot] = 0.0;
+            ++wc.n_atomics;
+            global_add(a, &edep[abs8(o.x, tx) * sXh + base_node], v);
+        }
+    }
+}
+
+// Everything a box still holds goes to HBM (wave end, or box B emptying).
+template <int WZ, int NC>
+__device__ __forceinline__ void flush_box(const TraceArgs &a, double *tile, const Origin &o, int lane, double *edep,
+                                          int sXh, int sYh, WaveCounters &wc, int coff, long gstride)
+{
+    double dv[2];
+    int dn[2];
+    for (int t = 0; t < Tile<WZ>::W; ++t)
+        retire_plane<WZ, 0, false, NC>(a, tile, o, o.x + t, lane, edep, sXh, sYh, wc, dv, dn, coff, gstride);
+}
+
+// Deferred plane sums of box A: x and y planes (WZ/8 entries per lane each) and, for WZ = 8, one z-plane entry.
+struct Deferred {
+    double vx[2] = {0.0, 0.0}, vy[2] = {0.0, 0.0}, vz = 0.0;
+    int nx[2] = {0, 0}, ny[2] = {0, 0}, nz = 0;
+};
+
+// Keep a box around its member lanes.  (lx, ly, lz) = the lane's low corner (haloed); `member` = the lane
+// counts for this box.  x and y follow by single planes with hysteresis: shift when a member sits on an edge
+// cell or outside, never shift a member out, never shift back on the next step.  z follows by single planes in
+// the same way (WZ = 8) or by aligned bricks (WZ = 16): shift by 8 when a member needs the next brick and no
+// member still needs the one that leaves.  Returns true when an origin moved.
+template <int WZ, bool DEFER, int NC>
+__device__ __forceinline__ bool follow_box(const TraceArgs &a, double *tile, Origin &o, bool member, int lx, int ly,
+                                           int lz, int lane, double *edep, int sXh, int sYh, WaveCounters &wc,
+                                           Deferred &d, int coff, long gstride)
+{
+    using T = Tile<WZ>;
+    bool moved = false;
+    const int rx = lx - o.x, ry = ly - o.y, rz = lz - o.z;
+    {   // x
+        constexpr int S = T::S;
+        if (any_lane(member && (unsigned)(rx - 1) >= (unsigned)(S - 1))) {
+            const bool below = any_lane(member && rx < 0), at_lo = any_lane(member && rx <= 0),
+                       near_lo = any_lane(member && rx <= 1);
+            const bool above = any_lane(member && rx > S), at_hi = any_lane(member && rx >= S),
+                       near_hi = any_lane(member && rx >= S - 1);
+            const bool want_down = below || (at_lo && !near_hi), want_up = above || (at_hi && !near_lo);
+            if (want_down && !at_hi) {
+                retire_plane<WZ, 0, DEFER, NC>(a, tile, o, o.x + T::W - 1, lane, edep, sXh, sYh, wc, d.vx, d.nx, coff, gstride);
+                o.x -= 1;
+                moved = true;
+            } else if (want_up && !at_lo) {
+                retire_plane<WZ, 0, DEFER, NC>(a, tile, o, o.x, lane, edep, sXh, sYh, wc, d.vx, d.nx, coff, gstride);
+                o.x += 1;
+                moved = true;
+            }
+        }
+    }
+    {   // y
+        constexpr int S = T::S;
+        if (any_lane(member && (unsigned)(ry - 1) >= (unsigned)(S - 1))) {
+            const bool below = any_lane(member && ry < 0), at_lo = any_lane(member && ry <= 0),
+                       near_lo = any_lane(member && ry <= 1);
+            const bool above = any_lane(member && ry > S), at_hi = any_lane(member && ry >= S),
+                       near_hi = any_lane(member && ry >= S - 1);
+            const bool want_down = below || (at_lo && !near_hi), want_up = above || (at_hi && !near_lo);
+            if (want_down && !at_hi) {
+                retire_plane<WZ, 1, DEFER, NC>(a, tile, o, o.y + T::W - 1, lane, edep, sXh, sYh, wc, d.vy, d.ny, coff, gstride);
+                o.y -= 1;
+                moved = true;
+            } else if (want_up && !at_lo) {
+                retire_plane<WZ, 1, DEFER, NC>(a, tile, o, o.y, lane, edep, sXh, sYh, wc, d.vy, d.ny, coff, gstride);
+                o.y += 1;
+                moved = true;
+            }
+        }
+    }
+    if (T::BRICK) {   // z by bricks: the lane's two z nodes are rz, rz + 1 in [0, 16)
+        if (any_lane(member && (unsigned)rz > (unsigned)T::SZ)) {
+            const bool below = any_lane(member && rz < 0), above = any_lane(member && rz > T::SZ);
+            const bool needs_lo = any_lane(member && rz <= 7), needs_hi = any_lane(member && rz >= 7);
+            if (below && !needs_hi) {
+                retire_zbrick<WZ>(a, tile, o, o.z + 8, lane, edep, sXh, sYh, wc);
+                o.z -= 8;
+                moved = true;
+            } else if (above && !needs_lo) {
+                retire_zbrick<WZ>(a, tile, o, o.z, lane, edep, sXh, sYh, wc);
+                o.z += 8;
+                moved = true;
+            }
+        }
+    } else {
+        constexpr int S = T::SZ;
+        if (any_lane(member && (unsigned)(rz - 1) >= (unsigned)(S - 1))) {
+            const bool below = any_lane(member && rz < 0), at_lo = any_lane(member && rz <= 0),
+                       near_lo = any_lane(member && rz <= 1);
+            const bool above = any_lane(member && rz > S), at_hi = any_lane(member && rz >= S),
+                       near_hi = any_lane(member && rz >= S - 1);
+            const bool want_down = below || (at_lo && !near_hi), want_up = above || (at_hi && !near_lo);
+            if (want_down && !at_hi) {
+                retire_zplane<WZ, DEFER, NC>(a, tile, o, o.z + WZ - 1, lane, edep, sXh, sYh, wc, d.vz, d.nz, coff, gstride);
+                o.z -= 1;
+                moved = true;
+            } else if (want_up && !at_lo) {
+                retire_zplane<WZ, DEFER, NC>(a, tile, o, o.z, lane, edep, sXh, sYh, wc, d.vz, d.nz, coff, gstride);
+                o.z += 1;
+                moved = true;
+            }
+        }
+    }
+    if (moved) wc.slabs_bsteps += 1u << 16;
+    return moved;
+}
+
+template <int WZ>
+__device__ __forceinline__ bool holds(const Origin &o, int lx, int ly, int lz)
+{
+    return (unsigned)(lx - o.x) <= (unsigned)Tile<WZ>::S && (unsigned)(ly - o.y) <= (unsigned)Tile<WZ>::S &&
+           (unsigned)(lz - o.z) <= (unsigned)Tile<WZ>::SZ;
+}
+
+// Is every cell a member of this box can occupy deep inside the grid (cbet_relocate.h, kRelocateDeep <= c <=
+// n - 3) -- and therefore also more than two cells from every exit plane?  A held lane's low corner lies in
+// [o, o + S], its cell index c is the low corner or one less.  Scalar arithmetic only.
+template <int WZ>
+__device__ __forceinline__ bool box_deep_inside(const Origin &o, int nx, int ny, int nz)
+{
+    using T = Tile<WZ>;
+    return o.x - 1 >= kRelocateDeep && o.x + T::S <= nx - 3 && o.y - 1 >= kRelocateDeep && o.y + T::S <= ny - 3 &&
+           o.z - 1 >= kRelocateDeep && o.z + T::SZ <= nz - 3;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The kernel.
+// ---------------------------------------------------------------------------------------------
+template <int WZ, bool GENERIC, int CBET>
+__global__ void __launch_bounds__(kWave) k_trace_window(const TraceArgs a)
+{
+    using T = Tile<WZ>;
+    constexpr bool IDX64 = GENERIC;
+    constexpr int NC = (CBET == 4) ? 4 : 1;
+    constexpr int NSLOT = 2 * T::N;                       // box A, box B
+    constexpr int NLDS = NSLOT + (NC - 1) * T::DT;        // + components 1.. of box A (field pass)
+    __shared__ double s_val[NLDS];
+    const int lane = threadIdx.x;
+
+    int beam, patch;
+    if (!work_item(a, blockIdx.x, beam, patch)) return;
+    // beam-resolved deposition (cbet_params.per_beam_grids): beam b accumulates into its own grid,
+    // edep[b * grid_stride ...]; otherwise every beam adds into the one grid (grid_stride = 0)
+    double *const edep = a.edep + (long)beam * a.grid_stride;
+    const bool absorb = GENERIC ? (a.absorption == 1) : true;   // def.cuh:118
+
+    Ray s;
+    const int li = patch * kWave + lane;
+    const int pre_raynum = li < a.nlive ? a.live[li] : -1;  // -1: hole in the 8x8 patch
+    bool alive = pre_raynum >= 0;
+    if (alive) alive = launch_ray(a, beam, pre_raynum, s);
+    const int launched = alive ? 1 : 0;
+
+    const int nx = a.nx, ny = a.ny, nz = a.nz;
+    const int sY = nz, sX = ny * nz;                      // node-table strides (elements)
+    const int sYh = nz + 2, sXh = (ny + 2) * (nz + 2);    // haloed edep strides (:5-7)
+    unsigned cell = alive ? (unsigned)((s.ci * ny + s.cj) * nz + s.ck) : 0u;
+    double fcx = (double)s.ci, fcy = (double)s.cj, fcz = (double)s.ck;   // the cell as the reference's (double)thisx
+    int nsteps = 0;
+    WaveCounters wc;
+
+    double *const tileA = s_val, *const tileB = s_val + T::N;
+    Origin oA{0, 0, 0}, oB{0, 0, 0};
+    bool homeB = false;     // per lane: the lane's deposits go to box B
+    bool b_active = false;  // wave-uniform
+    {
+        const unsigned long long m = __ballot(alive);
+        if (m == 0) return;  // whole bundle culled (cannot happen for a listed patch; cheap guard)
+        const int src = ((m >> 27) & 1ull) ? 27 : (__ffsll((long long)m) - 1);
+        for (int z = lane; z < NLDS; z += kWave) s_val[z] = 0.0;
+        oA.x = __builtin_amdgcn_readlane(s.ci, src) + 1 - T::W / 2;
+        oA.y = __builtin_amdgcn_readlane(s.cj, src) + 1 - T::W / 2;
+        oA.z = __builtin_amdgcn_readlane(s.ck, src) + 1 - 4;
+        if (T::BRICK) oA.z &= ~7;
+        __syncthreads();
+    }
+    // wave-uniform: every live lane was held by a box after the last step and both boxes lie deep inside the grid
+    bool deep = false;
+
+    // Software pipeline: the six stencil gathers of a step are issued at the END of the previous step (right
+    // after relocation, together with the kappa gather), so they are in flight during the whole deposit phase.
+    double st_xp = 0, st_xm = 0, st_yp = 0, st_ym = 0, st_zp = 0, st_zm = 0;
+    auto gather_stencil_faces = [&]() {
+        // :212-238 neighbours of the current node as table offsets, one-sided on the faces
+        const int oxm = (s.ci == 0) ? 0 : ((s.ci == nx - 1) ? -2 * sX : -sX);
+        const int oxp = (s.ci == 0) ? 2 * sX : ((s.ci == nx - 1) ? 0 : sX);
+        const int oym = (s.cj == 0) ? 0 : ((s.cj == ny - 1) ? -2 * sY : -sY);
+        const int oyp = (s.cj == 0) ? 2 * sY : ((s.cj == ny - 1) ? 0 : sY);
+        const int ozm = (s.ck == 0) ? 0 : ((s.ck == nz - 1) ? -2 : -1);
+        const int ozp = (s.ck == 0) ? 2 : ((s.ck == nz - 1) ? 0 : 1);
+        st_xp = node_load<IDX64>(a, a.ne3d, cell + oxp);
+        st_xm = node_load<IDX64>(a, a.ne3d, cell + oxm);
+        st_yp = node_load<IDX64>(a, a.ne3d, cell + oyp);
+        st_ym = node_load<IDX64>(a, a.ne3d, cell + oym);
+        st_zp = node_load<IDX64>(a, a.ne3d, cell + ozp);
+        st_zm = node_load<IDX64>(a, a.ne3d, cell + ozm);
+    };
+    auto gather_stencil_interior = [&]() {
+        // :254-265 six gathers from the node table, scalar strides added straight into the address
+        st_xp = node_load<IDX64>(a, a.ne3d, cell + sX);
+        st_xm = node_load<IDX64>(a, a.ne3d, cell - sX);
+        st_yp = node_load<IDX64>(a, a.ne3d, cell + sY);
+        st_ym = node_load<IDX64>(a, a.ne3d, cell - sY);
+        st_zp = node_load<IDX64>(a, a.ne3d, cell + 1);
+        st_zm = node_load<IDX64>(a, a.ne3d, cell - 1);
+    };
+    if (alive) gather_stencil_faces();
+    const double *const gk = CBET && a.gain ? a.gain + (long)beam * a.hsize : nullptr;  // this beam's gain grid
+    double gained = 0.0;                     // CBET: energy this lane's ray gained
+    Deferred dfr;
+    bool dfr_pending = false;                // wave-uniform: box A retired a plane in the previous step
+
+    // lane-dependent corner order (see the weights): which of an axis's two nodes a lane visits first
+    const bool flx = (lane & 1) != 0, fly = (lane & 2) != 0, flz = (lane & 8) != 0;
+
+    for (int tt = 0; tt < a.nt; ++tt) {                        // :207
+        if (__ballot(alive) == 0) break;
+        wc.steps_miss += 1u << 16;
+        double gx = 0.0, gy = 0.0, gz = 0.0;   // position relative to the (new) cell, in cells: xtemp - thisx
+        double kap = 0.0;
+        // ---- move, relocate, gather ---------------------------------------------------------------
+        bool slow = !deep;                     // wave-uniform
+        double fx = 0.0, fy = 0.0, fz = 0.0;
+        int qi = 0, qj = 0, qk = 0;
+        if (alive) {
+            // :268-273 kick then drift (stencil values gathered during the previous step)
+            s.vx -= a.xconst * (st_xp - st_xm);
+            s.vy -= a.yconst * (st_yp - st_ym);
+            s.vz -= a.zconst * (st_zp - st_zm);
+            s.px += s.vx * a.dt;
+            s.py += s.vy * a.dt;
+            s.pz += s.vz * a.dt;
+            // :276-278 position in cell units
+            fx = (s.px - a.xmin) * a.inv_dx;
+            fy = (s.py - a.ymin) * a.inv_dy;
+            fz = (s.pz - a.zmin) * a.inv_dz;
+            // :282-292 nearest-node update, deep-interior form (exact there; `far` = moved more than a cell)
+            bool far = false;
+            qi = relocate_deep_interior(s.ci, fcx, fx, far);
+            qj = relocate_deep_interior(s.cj, fcy, fy, far);
+            qk = relocate_deep_interior(s.ck, fcz, fz, far);
+            if (!slow) slow = far;             // per lane for now; made wave-uniform below
+        }
+        slow = !deep || any_lane(alive && slow);
+        if (alive) {
+            if (slow) {                        // near a face (or a far jump): closed form with the candidate bounds
+                s.ci = relocate_closed(s.ci, fx, nx);
+                s.cj = relocate_closed(s.cj, fy, ny);
+                s.ck = relocate_closed(s.ck, fz, nz);
+            } else {
+                s.ci = qi;
+                s.cj = qj;
+                s.ck = qk;
+            }
+            fcx = (double)s.ci;
+            fcy = (double)s.cj;
+            fcz = (double)s.ck;
+            cell = (unsigned)(__mul24(__mul24(s.ci, ny) + s.cj, nz) + s.ck);
+            // :296-298 absorption coefficient at the new node, then the NEXT step's stencil
+            if (absorb) kap = node_load<IDX64>(a, a.kap3d, cell);
+            if (slow) gather_stencil_faces(); else gather_stencil_interior();
+            gx = fx - fcx;                     // :319-321 (xtemp - thisx), the - 0.5 follows below
+            gy = fy - fcy;
+            gz = fz - fcz;
+        }
+        if (dfr_pending) {                     // scalar branch: last step's retired planes go to HBM now, behind this step's gathers
+            dfr_pending = false;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (dfr.vx[e] != 0.0) { global_add(a, &edep[dfr.nx[e]], dfr.vx[e]); dfr.vx[e] = 0.0; }
+                if (dfr.vy[e] != 0.0) { global_add(a, &edep[dfr.ny[e]], dfr.vy[e]); dfr.vy[e] = 0.0; }
+            }
+            if (!T::BRICK && dfr.vz != 0.0) { global_add(a, &edep[dfr.nz], dfr.vz); dfr.vz = 0.0; }
+        }
+        // ---- weights (:319-339) ---------------------------------------------------------------------
+        // Each weight is (Fz * Fy) * Fx * inc with F = (1-d) for the ray's own node along that axis and F = d
+        // for the neighbour on the `sign` side (:329-336).  The neighbour lies on the side of the offset's sign
+        // (:338-339), so a lane's two nodes per axis are {low, low + 1}, low = own - 1 iff the offset is negative.
+        // Corner order: the eight (node, weight) pairs are the same whatever order they are enumerated in, and
+        // every product keeps the reference's operand order.  Three lane bits swap which of an axis's two nodes
+        // is visited first, so rays a quarter cell apart that share all 8 target nodes hit different nodes in any
+        // one ds_add_f64 instead of serialising on one address: a patch row is lanes 8r..8r+7 and with 4 rays
+        // per zone the 16 lanes of rows 0-3 x columns 0-3 share a cell; bits 0 and 1 (column) and bit 3 (row)
+        // give those 16 lanes all 8 orders, two lanes each.
+        int lx = 0, ly = 0, lz = 0;            // the lane's low corner (haloed)
+        int X0 = 0, X1 = 0, Y0 = 0, Y1 = 0, Z0 = 0, Z1 = 0;
+        double wgt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;   // CBET = 4: the four field quantities this step deposits
+        if (alive) {
+            const double ox = gx - 0.5, oy = gy - 0.5, oz = gz - 0.5;
+            const double dm = 1.0 - fabs(ox), dn = 1.0 - fabs(oy), dl = 1.0 - fabs(oz);
+            const bool ngx = ox < 0, ngy = oy < 0, ngz = oz < 0;
+            lx = s.ci + 1 - (ngx ? 1 : 0);
+            ly = s.cj + 1 - (ngy ? 1 : 0);
+            lz = s.ck + 1 - (ngz ? 1 : 0);
+            const double ax_own = 1.0 - dm, ay_own = 1.0 - dn, az_own = 1.0 - dl;
+            const double Fx0 = flx ? dm : ax_own, Fx1 = flx ? ax_own : dm;
+            const double Fy0 = fly ? dn : ay_own, Fy1 = fly ? ay_own : dn;
+            const double Fz0 = flz ? dl : az_own, Fz1 = flz ? az_own : dl;
+            // first-visited node: the own node (the high one iff the offset is negative) unless flipped
+            const bool hx = ngx != flx, hy = ngy != fly, hz = ngz != flz;
+            X0 = lx + (hx ? 1 : 0); X1 = lx + (hx ? 0 : 1);
+            Y0 = ly + (hy ? 1 : 0); Y1 = ly + (hy ? 0 : 1);
+            Z0 = lz + (hz ? 1 : 0); Z1 = lz + (hz ? 0 : 1);
+            const double zy00 = Fz0 * Fy0, zy10 = Fz1 * Fy0, zy01 = Fz0 * Fy1, zy11 = Fz1 * Fy1;
+            // order (x,y,z) = (0,0,0) (1,0,0) (0,0,1) (1,0,1) (0,1,0) (1,1,0) (0,1,1) (1,1,1) -- :341-348 without the flips
+            wgt[0] = zy00 * Fx0;
+            wgt[1] = zy00 * Fx1;
+            wgt[2] = zy10 * Fx0;
+            wgt[3] = zy10 * Fx1;
+            wgt[4] = zy01 * Fx0;
+            wgt[5] = zy01 * Fx1;
+            wgt[6] = zy11 * Fx0;
+            wgt[7] = zy11 * Fx1;
+            if (CBET) {
+                // path length of the step; u_eff = the ray's energy averaged over the step
+                double ds = 0.0;
+                if (gk || CBET == 4) ds = sqrt(s.vx * s.vx + s.vy * s.vy + s.vz * s.vz) * a.dt;
+                double u_eff = s.uray;
+                if (gk) {
+                    // K at the eight deposit nodes, weighted like the deposit.  The pairwise tree makes the
+                    // sum independent of the corner order (the flips swap operands of commutative adds only).
+                    const int nX0 = __mul24(X0, sXh), nX1 = __mul24(X1, sXh), nY0 = __mul24(Y0, sYh), nY1 = __mul24(Y1, sYh);
+                    const double g0 = gain_load<IDX64>(a, gk, (unsigned)(nX0 + nY0 + Z0)), g1 = gain_load<IDX64>(a, gk, (unsigned)(nX1 + nY0 + Z0));
+                    const double g2 = gain_load<IDX64>(a, gk, (unsigned)(nX0 + nY0 + Z1)), g3 = gain_load<IDX64>(a, gk, (unsigned)(nX1 + nY0 + Z1));
+                    const double g4 = gain_load<IDX64>(a, gk, (unsigned)(nX0 + nY1 + Z0)), g5 = gain_load<IDX64>(a, gk, (unsigned)(nX1 + nY1 + Z0));
+                    const double g6 = gain_load<IDX64>(a, gk, (unsigned)(nX0 + nY1 + Z1)), g7 = gain_load<IDX64>(a, gk, (unsigned)(nX1 + nY1 + Z1));
+                    const double k01 = wgt[0] * g0 + wgt[1] * g1, k23 = wgt[2] * g2 + wgt[3] * g3;
+                    const double k45 = wgt[4] * g4 + wgt[5] * g5, k67 = wgt[6] * g6 + wgt[7] * g7;
+                    double x = ((k01 + k23) + (k45 + k67)) * ds;
+                    if (x > a.max_exponent) x = a.max_exponent;
+                    if (x < -a.max_exponent) x = -a.max_exponent;
+                    const double phi = phi_det(x);
+                    const double dg = s.uray * (x * phi);
+                    u_eff = s.uray * phi;
+                    gained += dg;
+                    s.uray = s.uray + dg;
+                }
+                if (CBET == 4) {
+                    q0 = u_eff * ds;
+                    q1 = u_eff * (s.vx * a.dt);
+                    q2 = u_eff * (s.vy * a.dt);
+                    q3 = u_eff * (s.vz * a.dt);
+                }
+            }
+            ++nsteps;
+        }
+        // ---- windows ----------------------------------------------------------------------------------
+        bool inbox;            // the lane deposits into LDS this step ...
+        int tile_off = 0;      // ... into this tile (offset in doubles)
+        {
+            // box A follows the lanes whose home it is
+            const bool memA = alive && !homeB;
+            bool moved = follow_box<WZ, true, NC>(a, tileA, oA, memA, lx, ly, lz, lane, edep, sXh, sYh, wc, dfr, NSLOT, a.comp_stride);
+            dfr_pending = dfr_pending || moved;
+            const bool inA = alive && holds<WZ>(oA, lx, ly, lz);
+            bool inB = false;
+            if (b_active) {  // scalar branch
+                wc.slabs_bsteps += 1u;
+                Deferred unused;
+                moved = follow_box<WZ, false, 1>(a, tileB, oB, alive && homeB, lx, ly, lz, lane, edep, sXh, sYh, wc, unused, 0, 0) || moved;
+                inB = alive && holds<WZ>(oB, lx, ly, lz);
+            }
+            // lanes that fell out of A look for a home in B; an idle B is re-created around the first of them
+            const bool lost = alive && !homeB && !inA;
+            const unsigned long long lost_mask = __builtin_amdgcn_ballot_w64(lost);
+            if (lost_mask != 0ull) {
+                if (!b_active) {
+                    const int src = __ffsll((long long)lost_mask) - 1;
+                    oB.x = __builtin_amdgcn_readlane(lx, src) - (T::W / 2 - 1);
+                    oB.y = __builtin_amdgcn_readlane(ly, src) - (T::W / 2 - 1);
+                    oB.z = __builtin_amdgcn_readlane(lz, src) - 3;
+                    if (T::BRICK) oB.z &= ~7;
+                    b_active = true;  // its tile is all zero: zeroed at start and flushed whenever it empties
+                    moved = true;
+                    inB = alive && holds<WZ>(oB, lx, ly, lz);
+                }
+                homeB = homeB || (lost && inB);
+            }
+            if (b_active) {
+                // a B lane that drifted out of B but back into A goes home
+                if (alive && homeB && !inB && inA) homeB = false;
+                if (!any_lane(alive && homeB)) {
+                    __builtin_amdgcn_wave_barrier();
+                    flush_box<WZ, 1>(a, tileB, oB, lane, edep, sXh, sYh, wc, 0, 0);
+                    b_active = false;
+                    moved = true;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const bool useB = alive && homeB && inB;
+            inbox = useB || (alive && !homeB && inA);
+            tile_off = useB ? T::N : 0;
+            const bool missed = any_lane(alive && !inbox);
+            if (missed) wc.steps_miss += 1u;
+            if (moved || missed || !deep)
+                deep = !missed && box_deep_inside<WZ>(oA, nx, ny, nz) && (!b_active || box_deep_inside<WZ>(oB, nx, ny, nz));
+        }
+        // ---- deposit (:305-311, :341-348) -------------------------------------------------------------
+        if (alive) {
+            double inc;
+            if (absorb) {
+                inc = kap * s.uray;
+                s.uray -= inc;
+            } else {
+                inc = s.uray;
+            }
+            if (CBET == 4) inc = q0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) wgt[c] = wgt[c] * inc;   // a_c * increment
+            if (inbox) {
+                const int x0 = (X0 & 7) * T::XS + tile_off, x1 = (X1 & 7) * T::XS + tile_off;
+                const int y0 = (Y0 & 7) * T::YS, y1 = (Y1 & 7) * T::YS;
+                const int z0 = Z0 & T::ZM, z1 = Z1 & T::ZM;
+                const int s00 = x0 + y0, s10 = x1 + y0, s01 = x0 + y1, s11 = x1 + y1;
+                auto add = [&](int slot, double w) {
+                    if (CBET_AUDIT(a, (unsigned)slot < (unsigned)NSLOT))
+                        __hip_atomic_fetch_add(&s_val[slot], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                };
+                add(s00 + z0, wgt[0]);
+                add(s10 + z0, wgt[1]);
+                add(s00 + z1, wgt[2]);
+                add(s10 + z1, wgt[3]);
+                add(s01 + z0, wgt[4]);
+                add(s11 + z0, wgt[5]);
+                add(s01 + z1, wgt[6]);
+                add(s11 + z1, wgt[7]);
+            } else {
+                const int nX0 = __mul24(X0, sXh), nX1 = __mul24(X1, sXh), nY0 = __mul24(Y0, sYh), nY1 = __mul24(Y1, sYh);
+                global_add(a, &edep[nX0 + nY0 + Z0], wgt[0]);
+                global_add(a, &edep[nX1 + nY0 + Z0], wgt[1]);
+                global_add(a, &edep[nX0 + nY0 + Z1], wgt[2]);
+                global_add(a, &edep[nX1 + nY0 + Z1], wgt[3]);
+                global_add(a, &edep[nX0 + nY1 + Z0], wgt[4]);
+                global_add(a, &edep[nX1 + nY1 + Z0], wgt[5]);
+                global_add(a, &edep[nX0 + nY1 + Z1], wgt[6]);
+                global_add(a, &edep[nX1 + nY1 + Z1], wgt[7]);
+                wc.n_atomics += 8;
+                ++wc.n_miss;
+            }
+            if (CBET == 4) {
+                // Displacement components: the ray's own node only -- box A's tiles, or HBM for a lane of
+                // box B / outside the boxes.
+                const int hi = s.ci + 1, hj = s.cj + 1, hk = s.ck + 1;
+                if (inbox && tile_off == 0) {
+                    const int own = T::slot_d(hi & 7, hj & 7, hk & T::ZM) + NSLOT;
+                    if (CBET_AUDIT(a, (unsigned)(own + 2 * T::DT) < (unsigned)NLDS)) {
+                        __hip_atomic_fetch_add(&s_val[own], q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(&s_val[own + T::DT], q2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(&s_val[own + 2 * T::DT], q3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                } else {
+                    const int own = __mul24(hi, sXh) + __mul24(hj, sYh) + hk;
+                    global_add(a, &edep[a.comp_stride + own], q1);
+                    global_add(a, &edep[2 * a.comp_stride + own], q2);
+                    global_add(a, &edep[3 * a.comp_stride + own], q3);
+                    wc.n_atomics += 3;
+                }
+            }
+            // ---- termination (:351-356) ----------------------------------------------------------------
+            if (s.uray <= s.ustop) alive = false;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // The six exit planes are compared only when the wave is not deep inside the grid: a lane held by a
+        // deep box is more than two cells from every face, far beyond the half cell of :352-354.
+        if (slow || !deep) {
+            const double *b = a.bounds;  // {xlo, xhi, ylo, yhi, zlo, zhi}
+            if (alive && (s.px < b[0] || s.px > b[1] || s.py < b[2] || s.py > b[3] || s.pz < b[4] || s.pz > b[5]))
+                alive = false;
+        }
+    }
+
+    // whatever is still in flight or in LDS
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        if (dfr.vx[e] != 0.0) global_add(a, &edep[dfr.nx[e]], dfr.vx[e]);
+        if (dfr.vy[e] != 0.0) global_add(a, &edep[dfr.ny[e]], dfr.vy[e]);
+    }
+    if (!T::BRICK && dfr.vz != 0.0) global_add(a, &edep[dfr.nz], dfr.vz);
+    __syncthreads();
+    flush_box<WZ, NC>(a, tileA, oA, lane, edep, sXh, sYh, wc, NSLOT, a.comp_stride);
+    if (b_active) flush_box<WZ, 1>(a, tileB, oB, lane, edep, sXh, sYh, wc, 0, 0);
+
+    if (CBET && a.beam_gain) {  // one fp64 atomic per wave
+        double t = gained;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, kWave);
+        if (lane == 0 && t != 0.0) atomicAdd(&a.beam_gain[beam], t);
+    }
+    // counters: one atomic per wave and counter
+    const int tot_steps = wave_sum(nsteps), tot_rays = wave_sum(launched), tot_at = wave_sum(wc.n_atomics),
+              tot_miss = wave_sum(wc.n_miss);
+    if (lane == 0) {
+        atomicAdd(&a.counters[kCntSteps], (unsigned long long)tot_steps);
+        atomicAdd(&a.counters[kCntRays], (unsigned long long)tot_rays);
+        atomicAdd(&a.counters[kCntGlobalAtomics], (unsigned long long)tot_at);
+        atomicAdd(&a.counters[kCntEvictions], (unsigned long long)tot_miss);
+        atomicAdd(&a.counters[kCntWaveSteps], (unsigned long long)(wc.steps_miss >> 16));
+        atomicAdd(&a.counters[kCntWaveStepsMiss], (unsigned long long)(wc.steps_miss & 0xFFFFu));
+        atomicAdd(&a.counters[kCntWaveStepsWide], (unsigned long long)(wc.slabs_bsteps & 0xFFFFu));
+        atomicAdd(&a.counters[kCntSlabsRetired], (unsigned long long)(wc.slabs_bsteps >> 16));
+    }
+}
+
+}  // namespace
+
+hipError_t launch_trace_window(const TraceArgs &a, bool force_idx64, hipStream_t stream)
+{
+    const long waves = (a.total_bundles - a.shard_index + a.shard_count - 1) / a.shard_count;
+    if (waves <= 0) return hipSuccess;
+    const dim3 grid((unsigned)waves), block(kWave);
+    // 32-bit byte offsets into the node tables -- and, with the CBET hooks, into a beam's haloed gain grid
+    const unsigned long long table_bytes = 8ull * (a.gain ? (unsigned long long)a.hsize : (unsigned long long)a.nx * a.ny * a.nz);
+    const bool generic = force_idx64 || table_bytes >= (1ull << 32) || a.absorption != 1;
+    if (a.quantity != 0) {  // the fused four-component field pass (single z-planes: four tiles per wave must fit)
+        if (generic) hipLaunchKernelGGL((k_trace_window<8, true, 4>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((k_trace_window<8, false, 4>), grid, block, 0, stream, a);
+    } else if (a.gain || a.beam_gain) {
+        if (generic) hipLaunchKernelGGL((k_trace_window<16, true, 1>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((k_trace_window<16, false, 1>), grid, block, 0, stream, a);
+    } else {
+        if (generic) hipLaunchKernelGGL((k_trace_window<16, true, 0>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((k_trace_window<16, false, 0>), grid, block, 0, stream, a);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace cbet

@@ -55,9 +55,7 @@ class RayTracer:
         return torch.zeros(shape, dtype=torch.float64, device=self.device)
 
     def launch(self, edep, shard_index=0, shard_count=1, beam_lo=0, beam_hi=None,
-               kernel_variant=None, lds_window_log2=None, lds_copies_log2=None, lds_prereduce=None,
-               lds_corner_flip=None, lds_two_boxes=None, force_wide_index=None, xcd_order=None,
-               use_host_trig=True):
+               kernel_variant=None, force_wide_index=None, use_host_trig=True):
         """Enqueue one launch_ray_XYZ on torch's current stream, accumulating into `edep`."""
         per_beam = edep.dim() == 4
         want = ((self.params.nbeams,) + self.grid_shape) if per_beam else self.grid_shape
@@ -68,20 +66,8 @@ class RayTracer:
                              shard_index=shard_index, shard_count=shard_count)
         if kernel_variant is not None:
             p.kernel_variant = kernel_variant
-        if lds_window_log2 is not None:
-            p.lds_window_log2 = lds_window_log2
-        if lds_copies_log2 is not None:
-            p.lds_copies_log2 = lds_copies_log2
-        if lds_prereduce is not None:
-            p.lds_prereduce = lds_prereduce
-        if lds_corner_flip is not None:
-            p.lds_corner_flip = lds_corner_flip
-        if lds_two_boxes is not None:
-            p.lds_two_boxes = lds_two_boxes
         if force_wide_index is not None:
             p.force_wide_index = force_wide_index
-        if xcd_order is not None:
-            p.xcd_order = xcd_order
         d = self.derived
         stream = torch.cuda.current_stream(self.device).cuda_stream
         api.launch_ray_XYZ(0, d.nindices, self.d_te, self.d_r, self.d_ne, edep,
@@ -101,7 +87,7 @@ class RayTracer:
         api.tabulate_plasma(self.ctx, self.params, self.d_te, self.d_r, self.d_ne, stream)
 
     def launch_cbet(self, out, gain_params, fields=False, gain=None, beam_gain=None, shard_index=0,
-                    shard_count=1, ne3d=None, kappa3d=None, lds_two_boxes=None, beam_lo=0, beam_hi=None):
+                    shard_count=1, ne3d=None, kappa3d=None, beam_lo=0, beam_hi=None):
         """One trace with the CBET hooks on torch's current stream (node tables must be filled:
         tabulate(), or pass ne3d / kappa3d).  fields=False: deposit the absorbed energy into `out`
         ((n+2)^3 grid or nbeams of them); fields=True: the fused field pass, `out` = new_fields()."""
@@ -119,8 +105,6 @@ class RayTracer:
         p = self.params.copy(per_beam_grids=1 if per_beam else 0, beam_lo=beam_lo,
                              beam_hi=self.params.nbeams if beam_hi is None else beam_hi,
                              shard_index=shard_index, shard_count=shard_count)
-        if lds_two_boxes is not None:
-            p.lds_two_boxes = lds_two_boxes
         d = self.derived
         stream = torch.cuda.current_stream(self.device).cuda_stream
         api.trace_cbet(0, d.nindices, ne3d, kappa3d, gain, api.DEPOSIT_FIELDS if fields else api.DEPOSIT_ENERGY, out,

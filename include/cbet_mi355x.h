@@ -38,7 +38,7 @@ extern "C" {
 #define CBET_KERNEL_DEFAULT 0        /* the library's best parity-exact kernel */
 #define CBET_KERNEL_GLOBAL_ATOMICS 1 /* one ray per lane, 8 global fp64 atomics per step */
 #define CBET_KERNEL_LDS_COMBINE 2    /* wave-private tagged LDS write-combining of the deposits */
-#define CBET_KERNEL_LDS_WINDOW 3     /* wave-private dense LDS window that follows the ray bundle */
+#define CBET_KERNEL_LDS_WINDOW 3     /* wave-private dense LDS windows that follow the ray bundle (the default) */
 
 /*
  * Run-time counterpart of def.cuh's compile-time configuration (def.cuh:33-131).  Fill with
@@ -64,28 +64,14 @@ typedef struct cbet_params {
                                  /* bundle g is traced iff g % shard_count == shard_index      */
                                  /* (shard_count<=1: everything)                               */
     int kernel_variant;          /* CBET_KERNEL_*                                              */
-    int lds_window_log2;         /* LDS variants: log2 of the cubic window edge (3 or 4; 0=auto)*/
-    int lds_copies_log2;         /* LDS_WINDOW: log2 of privatised tile copies (0..2; -1 = auto)*/
-    int lds_prereduce;           /* LDS_WINDOW: levels of in-register lane merging (0..2; -1 = auto)*/
-    int lds_corner_flip;         /* LDS_WINDOW: lane-dependent corner order (0/1; -1 = auto)   */
-    int lds_two_boxes;           /* LDS_WINDOW: second window for lanes that leave the first   */
-                                 /* (0/1; -1 = auto; implies 1 copy, no pre-reduction, flip)   */
     int force_wide_index;        /* test hook: use the 64-bit node-table indexing path that grids  */
                                  /* with 8*nx*ny*nz >= 2^32 bytes (n > 812) need, at any size      */
-    int xcd_order;               /* workgroup order: 1 = consecutive bundles on one XCD, 0 = plain, */
-                                 /* -1 = auto                                                       */
     int per_beam_grids;          /* 1: beam-resolved deposition -- edep is nbeams grids of            */
                                  /* (nx+2)(ny+2)(nz+2) doubles and beam b adds into grid b (what a    */
                                  /* cross-beam stage needs: every beam's own field); 0: one grid      */
     int patch_order;             /* 1 = longest first: a beam's patches are listed by descending      */
                                  /* launch radius (outer rays take ~3x the steps of central ones);     */
                                  /* 0 = Morton curve.  Part of the geometry a context is created for.  */
-    int order_phases;            /* work-item order.  1 (and -1 = auto): beam-major -- beam by beam,   */
-                                 /* each beam's patches longest first.  P > 1: the launch runs in P    */
-                                 /* phases, phase p tracing the p-th slice of every beam's patch list  */
-                                 /* (a globally longest-first order that shortens a launch's tail);    */
-                                 /* measured slower (P = 2: -9 %): it bunches every beam's central     */
-                                 /* bundles, whose deposits hit the same cells, into the last phase.   */
 } cbet_params;
 
 /* Quantities the reference derives in def.cuh / main.cu:156-161, evaluated in the same order. */
@@ -114,9 +100,9 @@ typedef struct cbet_counters {
                                          /* LDS_WINDOW: ray-steps that fell outside the window */
     unsigned long long wave_steps;       /* integrator iterations per wavefront (64 lane slots each) */
     unsigned long long wave_steps_miss;  /* LDS_WINDOW: wave-steps in which some lane missed the window */
-    unsigned long long wave_steps_wide;  /* LDS_WINDOW: of those, the bundle was wider than the window; */
-                                         /* with two boxes: wave-steps in which the second box was live */
-    unsigned long long slabs_retired;    /* LDS_WINDOW: window slabs flushed because the box moved      */
+    unsigned long long wave_steps_wide;  /* LDS_WINDOW: wave-steps in which the second box was live     */
+    unsigned long long slabs_retired;    /* LDS_WINDOW: wave-steps in which a box origin moved (planes / */
+                                         /* z-bricks written back to HBM)                               */
 } cbet_counters;
 
 typedef struct cbet_context cbet_context; /* per-device workspace: node tables, ray list, counters */
@@ -131,12 +117,11 @@ int cbet_derive(const cbet_params *p, cbet_derived *d);
 
 /*
  * The beam-independent launch list, in the order the trace kernel consumes it.  The beam cross
- * section is cut into 8x8-ray patches (Morton order); 64 consecutive entries = one patch = one ray
+ * section is cut into 8x8-ray patches (cbet_params.patch_order); 64 consecutive entries = one patch = one ray
  * bundle = one wavefront.  An entry is the thread-ray id (launch_ray_XZ.cu:125,156) of that ray,
  * or -1 for a hole: a ray the reference launch shape never visits or one that fails init()'s
- * beam-radius test (:94,114).  Work items g are (beam, patch) pairs ordered in phases
- * (cbet_params.order_phases: phase by phase, beam by beam, patch by patch); item g is traced by shard
- * g % shard_count.
+ * beam-radius test (:94,114).  Work items g are (beam, patch) pairs, beam by beam, patch by patch;
+ * item g is traced by shard g % shard_count.
  * Writes min(n, cap) entries to out (may be NULL) and n to *count.
  */
 int cbet_live_ray_list(const cbet_params *p, int *out, long cap, long *count);

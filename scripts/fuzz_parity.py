@@ -1,5 +1,5 @@
 """Randomised parity sweep on the GPU: small random grids (ragged, tiny, face-hugging), beam subsets, rays per
-zone, absorption on/off, sharding, beam-resolved grids, kernel variants and window knobs -- every case against
+zone, absorption on/off, sharding, beam-resolved grids, all three kernel formulations -- every case against
 the CPU oracle (SURVEY 8(c) metric <= 1e-9, equal ray-step counts).  usage: python scripts/fuzz_parity.py [cases=40] [seed=1]"""
 import os, sys
 import numpy as np, torch
@@ -24,13 +24,6 @@ for case in range(cases):
     absorb = int(rng.random() < 0.8)
     variant = int(rng.choice([0, 1, 2, 3]))
     kw = {}
-    if variant in (0, 3):
-        mode = rng.integers(0, 4)
-        if mode == 1: kw = dict(lds_two_boxes=0)
-        elif mode == 2: kw = dict(lds_two_boxes=0, lds_corner_flip=0, lds_copies_log2=int(rng.integers(0, 3)), lds_prereduce=int(rng.integers(0, 3)))
-        elif mode == 3: kw = dict(lds_window_log2=4)
-    elif variant == 2 and rng.random() < 0.5:
-        kw = dict(lds_window_log2=4)
     wide = int(rng.random() < 0.2)
     shards = int(rng.choice([1, 1, 2, 3]))
     per_beam = bool(rng.random() < 0.3)
