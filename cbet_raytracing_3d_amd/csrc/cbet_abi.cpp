@@ -204,6 +204,7 @@ struct cbet_context {
     cbet_params p{};
     cbet_derived d{};
     double *ne3d = nullptr, *kap3d = nullptr;
+    StepRecord *steprec = nullptr;      // per-node step records of the LDS_WINDOW kernel, rebuilt by every launch that uses them
     double *xlaunch = nullptr, *ylaunch = nullptr;
     double *bounds = nullptr;  // {xlo,xhi,ylo,yhi,zlo,zhi}
     int *live = nullptr;
@@ -363,6 +364,7 @@ int cbet_context_destroy(cbet_context *ctx)
     (void)hipSetDevice(ctx->gpu);
     (void)hipFree(ctx->ne3d);
     (void)hipFree(ctx->kap3d);
+    (void)hipFree(ctx->steprec);
     (void)hipFree(ctx->xlaunch);
     (void)hipFree(ctx->ylaunch);
     (void)hipFree(ctx->bounds);
@@ -403,6 +405,7 @@ int cbet_context_create(cbet_context **out, const cbet_params *p, int gpu)
     };
     if ((e = hipMalloc((void **)&ctx->ne3d, nodes * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(ne3d)");
     if ((e = hipMalloc((void **)&ctx->kap3d, nodes * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(kappa3d)");
+    if ((e = hipMalloc((void **)&ctx->steprec, nodes * sizeof(StepRecord))) != hipSuccess) return bail(e, "hipMalloc(step records)");
     if ((e = hipMalloc((void **)&ctx->xlaunch, xl.size() * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(xlaunch)");
     if ((e = hipMalloc((void **)&ctx->ylaunch, yl.size() * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(ylaunch)");
     if ((e = hipMalloc((void **)&ctx->bounds, 6 * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(bounds)");
@@ -573,6 +576,16 @@ static int trace_impl(int b, unsigned nindices, const double *ne3d, const double
     a.max_exponent = hooks.max_exponent; a.beam_gain = hooks.beam_gain;
     DeviceGuard guard;
     CBET_HIP(hipSetDevice(ctx->gpu));
+    if (variant == CBET_KERNEL_LDS_WINDOW) {
+        // the shipped kernel reads one 32-byte record per node; built here because only the launch knows both
+        // the tables (possibly the caller's) and the gradient constants (0.15 ms at 256^3, part of every pass)
+        StepTableArgs t{};
+        t.nx = p->nx; t.ny = p->ny; t.nz = p->nz;
+        t.xconst = xconst; t.yconst = yconst; t.zconst = zconst;
+        t.ne3d = a.ne3d; t.kap3d = a.kap3d; t.rec = ctx->steprec;
+        CBET_HIP(launch_step_table(t, (hipStream_t)stream));
+        a.steprec = ctx->steprec;
+    }
     CBET_HIP(launch_trace(a, variant, p->force_wide_index != 0, (hipStream_t)stream));
     return CBET_OK;
 }

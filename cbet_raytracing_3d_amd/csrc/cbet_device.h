@@ -38,6 +38,21 @@ struct TabulateArgs {
     double *ne3d, *kap3d;       // device, nx*ny*nz each
 };
 
+// What a ray-step of the shipped integrator reads at its (new) node, as ONE 32-byte record: the three velocity
+// kicks of launch_ray_XZ.cu:268-270 -- xconst * (ne(x+1) - ne(x-1)) with the one-sided face rule of :212-238,
+// the very products the reference forms, tabulated once per node -- and the absorption coefficient of :296-305
+// (kappa3d).  One aligned 32-byte gather per lane and step instead of seven 8-byte gathers from five lines.
+struct StepRecord {
+    double kx, ky, kz, kap;
+};
+
+struct StepTableArgs {
+    int nx, ny, nz;
+    double xconst, yconst, zconst;          // main.cu:156-159
+    const double *ne3d, *kap3d;             // node tables, nx*ny*nz each
+    StepRecord *rec;                        // out, nx*ny*nz
+};
+
 // Everything the trace kernel needs, passed by value as the kernel argument.
 struct TraceArgs {
     // grid (def.cuh:35-53)
@@ -63,6 +78,7 @@ struct TraceArgs {
     int shard_index, shard_count;
     // tables
     const double *ne3d, *kap3d;
+    const StepRecord *steprec;              // LDS_WINDOW kernel: per-node step records built from the two tables
     const double *beam_norm, *bbeam_norm, *pow_r, *phase_r;
     double *edep;
     long grid_stride;                       // 0: one grid for all beams; else doubles between per-beam grids
@@ -97,6 +113,7 @@ struct GainArgs {
 };
 
 hipError_t launch_tabulate(const TabulateArgs &a, hipStream_t stream);
+hipError_t launch_step_table(const StepTableArgs &a, hipStream_t stream);
 hipError_t audit_violations(unsigned long long *out, bool reset, hipStream_t stream);
 // variant: CBET_KERNEL_GLOBAL_ATOMICS, _LDS_COMBINE (cbet_kernels.hip) or _LDS_WINDOW (cbet_trace_window.hip)
 hipError_t launch_trace(const TraceArgs &a, int variant, bool force_idx64, hipStream_t stream);

@@ -78,6 +78,33 @@ __global__ void __launch_bounds__(256) k_tabulate(const TabulateArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Step records (cbet_device.h StepRecord): one thread per node, z fastest.  Bound: HBM, 16 B read (plus
+// neighbour lines from cache) and 32 B written per node.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_step_table(const StepTableArgs a)
+{
+    const long total = (long)a.nx * a.ny * a.nz;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long sY = a.nz, sX = (long)a.ny * a.nz;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int k = (int)(idx % a.nz);
+        const long ij = idx / a.nz;
+        const int j = (int)(ij % a.ny);
+        const int i = (int)(ij / a.ny);
+        // launch_ray_XZ.cu:212-238 : neighbours this+-1, one-sided on the faces (0 -> (0, 2), n-1 -> (n-3, n-1))
+        const long oxm = (i == 0) ? 0 : ((i == a.nx - 1) ? -2 * sX : -sX), oxp = (i == 0) ? 2 * sX : ((i == a.nx - 1) ? 0 : sX);
+        const long oym = (j == 0) ? 0 : ((j == a.ny - 1) ? -2 * sY : -sY), oyp = (j == 0) ? 2 * sY : ((j == a.ny - 1) ? 0 : sY);
+        const long ozm = (k == 0) ? 0 : ((k == a.nz - 1) ? -2 : -1), ozp = (k == 0) ? 2 : ((k == a.nz - 1) ? 0 : 1);
+        StepRecord r;
+        r.kx = a.xconst * (a.ne3d[idx + oxp] - a.ne3d[idx + oxm]);   // :268
+        r.ky = a.yconst * (a.ne3d[idx + oyp] - a.ne3d[idx + oym]);   // :269
+        r.kz = a.zconst * (a.ne3d[idx + ozp] - a.ne3d[idx + ozm]);   // :270
+        r.kap = a.kap3d[idx];
+        a.rec[idx] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Wave-private LDS write-combining window for the deposits.
 //
 // slot(i,j,k) = the node's haloed indices taken modulo W per axis (a W^3 torus), tag = the node's
@@ -324,6 +351,15 @@ hipError_t launch_tabulate(const TabulateArgs &a, hipStream_t stream)
     if (blocks > 256 * 16) blocks = 256 * 16;  // 256 CUs x 16 blocks, grid-stride the rest
     const size_t lds = sizeof(double) * 3 * (size_t)a.nprofile;
     hipLaunchKernelGGL(k_tabulate, dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_step_table(const StepTableArgs &a, hipStream_t stream)
+{
+    const long total = (long)a.nx * a.ny * a.nz;
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_step_table, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -145,7 +145,11 @@ __device__ __forceinline__ void global_add(const TraceArgs &a, double *p, double
     (void)a;
 #endif
     // native global_atomic_add_f64, no CAS loop (checked in the ISA)
+#ifndef CBET_EXP_NO_ATOMICS   // TEMPORARY timing-only experiment
     unsafeAtomicAdd(p, v);
+#else
+    (void)p; (void)v;
+#endif
 }
 
 __device__ __forceinline__ int wave_sum(int v)

@@ -41,9 +41,11 @@ struct Tile {
     static constexpr int ZM = WZ - 1;
     // Padded layout (doubles): ds_add_f64 costs the CU ~8 cycles when the lanes' addresses fall on different
     // bank pairs, +2 per lane sharing a bank, +3 per lane sharing an address (scripts/ubench/lds_atomic.hip),
-    // and a bundle's footprint is a few nodes wide per axis: rows are padded by one entry, planes by four.
-    static constexpr int YS = WZ + 1;
-    static constexpr int XS = W * YS + 4;
+    // and a bundle's footprint is a few nodes wide per axis, so rows and planes are padded.
+    // The strides are chosen so that the 27 nodes of any 3 x 3 x 3 block fall on 27 different bank pairs for WZ = 16
+    // ((149 dx + 18 dy + dz) mod 32 takes 27 distinct values); the smaller tile keeps the compact (9, 76) pair.
+    static constexpr int YS = WZ == 16 ? 18 : WZ + 1;
+    static constexpr int XS = WZ == 16 ? 149 : W * YS + 4;
     static constexpr int N = W * XS;            // doubles per tile
     static constexpr int S = W - 2;             // largest x / y offset of a lane's low corner inside the box
     static constexpr int SZ = WZ - 2;           // ... z offset
@@ -202,91 +204,61 @@ struct Deferred {
     int nx[2] = {0, 0}, ny[2] = {0, 0}, nz = 0;
 };
 
-// Keep a box around its member lanes.  (lx, ly, lz) = the lane's low corner (haloed); `member` = the lane
-// counts for this box.  x and y follow by single planes with hysteresis: shift when a member sits on an edge
-// cell or outside, never shift a member out, never shift back on the next step.  z follows by single planes in
-// the same way (WZ = 8) or by aligned bricks (WZ = 16): shift by 8 when a member needs the next brick and no
-// member still needs the one that leaves.  Returns true when an origin moved.
+// Wave-uniform decision of the hysteresis rule for one axis followed by single planes: -1 / +1 = shift the
+// origin down / up, 0 = stay.  r = the lane's low-corner offset from the origin, mm = ballot of the box's member
+// lanes, S = the largest offset at which a lane's two nodes still lie inside.  Shift when a member sits on an
+// edge cell or outside, never shift a member out, never shift back on the next step.
+__device__ __forceinline__ int follow_plane_axis(int r, unsigned long long mm, int S)
+{
+    if ((__builtin_amdgcn_ballot_w64((unsigned)(r - 1) >= (unsigned)(S - 1)) & mm) == 0ull) return 0;
+    const bool below = (__builtin_amdgcn_ballot_w64(r < 0) & mm) != 0ull, at_lo = (__builtin_amdgcn_ballot_w64(r <= 0) & mm) != 0ull,
+               near_lo = (__builtin_amdgcn_ballot_w64(r <= 1) & mm) != 0ull;
+    const bool above = (__builtin_amdgcn_ballot_w64(r > S) & mm) != 0ull, at_hi = (__builtin_amdgcn_ballot_w64(r >= S) & mm) != 0ull,
+               near_hi = (__builtin_amdgcn_ballot_w64(r >= S - 1) & mm) != 0ull;
+    const bool want_down = below || (at_lo && !near_hi), want_up = above || (at_hi && !near_lo);
+    return (want_down && !at_hi) ? -1 : ((want_up && !at_lo) ? 1 : 0);
+}
+
+// ... and for z followed by aligned bricks (WZ = 16): the lane's two z nodes are r, r + 1 in [0, 16); shift by a
+// brick when a member needs the next one and no member still needs the one that leaves.
+__device__ __forceinline__ int follow_brick_axis(int r, unsigned long long mm)
+{
+    if ((__builtin_amdgcn_ballot_w64((unsigned)r > 14u) & mm) == 0ull) return 0;
+    const bool below = (__builtin_amdgcn_ballot_w64(r < 0) & mm) != 0ull, above = (__builtin_amdgcn_ballot_w64(r > 14) & mm) != 0ull;
+    const bool needs_lo = (__builtin_amdgcn_ballot_w64(r <= 7) & mm) != 0ull, needs_hi = (__builtin_amdgcn_ballot_w64(r >= 7) & mm) != 0ull;
+    return (below && !needs_hi) ? -1 : ((above && !needs_lo) ? 1 : 0);
+}
+
+// Keep a box around its member lanes: (lx, ly, lz) = the lane's low corner (haloed), mm = ballot of the lanes
+// that count for this box.  The decisions are taken first, as scalars; the planes that leave are then written
+// back and the origin is moved by plain scalar arithmetic outside every divergent region (so that it stays in
+// scalar registers).  Returns true when the origin moved.
 template <int WZ, bool DEFER, int NC>
-__device__ __forceinline__ bool follow_box(const TraceArgs &a, double *tile, Origin &o, bool member, int lx, int ly,
-                                           int lz, int lane, double *edep, int sXh, int sYh, WaveCounters &wc,
+__device__ __forceinline__ bool follow_box(const TraceArgs &a, double *tile, Origin &o, unsigned long long mm, int lx,
+                                           int ly, int lz, int lane, double *edep, int sXh, int sYh, WaveCounters &wc,
                                            Deferred &d, int coff, long gstride)
 {
     using T = Tile<WZ>;
-    bool moved = false;
-    const int rx = lx - o.x, ry = ly - o.y, rz = lz - o.z;
-    {   // x
-        constexpr int S = T::S;
-        if (any_lane(member && (unsigned)(rx - 1) >= (unsigned)(S - 1))) {
-            const bool below = any_lane(member && rx < 0), at_lo = any_lane(member && rx <= 0),
-                       near_lo = any_lane(member && rx <= 1);
-            const bool above = any_lane(member && rx > S), at_hi = any_lane(member && rx >= S),
-                       near_hi = any_lane(member && rx >= S - 1);
-            const bool want_down = below || (at_lo && !near_hi), want_up = above || (at_hi && !near_lo);
-            if (want_down && !at_hi) {
-                retire_plane<WZ, 0, DEFER, NC>(a, tile, o, o.x + T::W - 1, lane, edep, sXh, sYh, wc, d.vx, d.nx, coff, gstride);
-                o.x -= 1;
-                moved = true;
-            } else if (want_up && !at_lo) {
-                retire_plane<WZ, 0, DEFER, NC>(a, tile, o, o.x, lane, edep, sXh, sYh, wc, d.vx, d.nx, coff, gstride);
-                o.x += 1;
-                moved = true;
-            }
-        }
-    }
-    {   // y
-        constexpr int S = T::S;
-        if (any_lane(member && (unsigned)(ry - 1) >= (unsigned)(S - 1))) {
-            const bool below = any_lane(member && ry < 0), at_lo = any_lane(member && ry <= 0),
-                       near_lo = any_lane(member && ry <= 1);
-            const bool above = any_lane(member && ry > S), at_hi = any_lane(member && ry >= S),
-                       near_hi = any_lane(member && ry >= S - 1);
-            const bool want_down = below || (at_lo && !near_hi), want_up = above || (at_hi && !near_lo);
-            if (want_down && !at_hi) {
-                retire_plane<WZ, 1, DEFER, NC>(a, tile, o, o.y + T::W - 1, lane, edep, sXh, sYh, wc, d.vy, d.ny, coff, gstride);
-                o.y -= 1;
-                moved = true;
-            } else if (want_up && !at_lo) {
-                retire_plane<WZ, 1, DEFER, NC>(a, tile, o, o.y, lane, edep, sXh, sYh, wc, d.vy, d.ny, coff, gstride);
-                o.y += 1;
-                moved = true;
-            }
-        }
-    }
-    if (T::BRICK) {   // z by bricks: the lane's two z nodes are rz, rz + 1 in [0, 16)
-        if (any_lane(member && (unsigned)rz > (unsigned)T::SZ)) {
-            const bool below = any_lane(member && rz < 0), above = any_lane(member && rz > T::SZ);
-            const bool needs_lo = any_lane(member && rz <= 7), needs_hi = any_lane(member && rz >= 7);
-            if (below && !needs_hi) {
-                retire_zbrick<WZ>(a, tile, o, o.z + 8, lane, edep, sXh, sYh, wc);
-                o.z -= 8;
-                moved = true;
-            } else if (above && !needs_lo) {
-                retire_zbrick<WZ>(a, tile, o, o.z, lane, edep, sXh, sYh, wc);
-                o.z += 8;
-                moved = true;
-            }
-        }
+    const int dx = follow_plane_axis(lx - o.x, mm, T::S);
+    if (dx != 0)
+        retire_plane<WZ, 0, DEFER, NC>(a, tile, o, dx < 0 ? o.x + T::W - 1 : o.x, lane, edep, sXh, sYh, wc, d.vx, d.nx, coff, gstride);
+    o.x += dx;
+    const int dy = follow_plane_axis(ly - o.y, mm, T::S);
+    if (dy != 0)
+        retire_plane<WZ, 1, DEFER, NC>(a, tile, o, dy < 0 ? o.y + T::W - 1 : o.y, lane, edep, sXh, sYh, wc, d.vy, d.ny, coff, gstride);
+    o.y += dy;
+    int dz;
+    if (T::BRICK) {
+        dz = 8 * follow_brick_axis(lz - o.z, mm);
+        if (dz != 0) retire_zbrick<WZ>(a, tile, o, dz < 0 ? o.z + 8 : o.z, lane, edep, sXh, sYh, wc);
     } else {
-        constexpr int S = T::SZ;
-        if (any_lane(member && (unsigned)(rz - 1) >= (unsigned)(S - 1))) {
-            const bool below = any_lane(member && rz < 0), at_lo = any_lane(member && rz <= 0),
-                       near_lo = any_lane(member && rz <= 1);
-            const bool above = any_lane(member && rz > S), at_hi = any_lane(member && rz >= S),
-                       near_hi = any_lane(member && rz >= S - 1);
-            const bool want_down = below || (at_lo && !near_hi), want_up = above || (at_hi && !near_lo);
-            if (want_down && !at_hi) {
-                retire_zplane<WZ, DEFER, NC>(a, tile, o, o.z + WZ - 1, lane, edep, sXh, sYh, wc, d.vz, d.nz, coff, gstride);
-                o.z -= 1;
-                moved = true;
-            } else if (want_up && !at_lo) {
-                retire_zplane<WZ, DEFER, NC>(a, tile, o, o.z, lane, edep, sXh, sYh, wc, d.vz, d.nz, coff, gstride);
-                o.z += 1;
-                moved = true;
-            }
-        }
+        dz = follow_plane_axis(lz - o.z, mm, T::SZ);
+        if (dz != 0)
+            retire_zplane<WZ, DEFER, NC>(a, tile, o, dz < 0 ? o.z + WZ - 1 : o.z, lane, edep, sXh, sYh, wc, d.vz, d.nz, coff, gstride);
     }
-    if (moved) wc.slabs_bsteps += 1u << 16;
+    o.z += dz;
+    const bool moved = (dx | dy | dz) != 0;
+    wc.slabs_bsteps += moved ? (1u << 16) : 0u;
     return moved;
 }
 
@@ -311,13 +283,23 @@ __device__ __forceinline__ bool box_deep_inside(const Origin &o, int nx, int ny,
 // ---------------------------------------------------------------------------------------------
 // The kernel.
 // ---------------------------------------------------------------------------------------------
+#define CBET_BALLOT(cond) __builtin_amdgcn_ballot_w64(cond)
+#ifndef CBET_MIN_WAVES
+#define CBET_MIN_WAVES 1
+#endif
+
+constexpr double kNearTol = 0.5001;   // launch_ray_XZ.cu:132, the nearest-node tolerance
+constexpr double kFarJump = 1.4998;   // relocate_deep_interior's validity bound on |f - cell|
+
 template <int WZ, bool GENERIC, int CBET>
-__global__ void __launch_bounds__(kWave) k_trace_window(const TraceArgs a)
+__global__ void __launch_bounds__(kWave, CBET_MIN_WAVES) k_trace_window(const TraceArgs a)
 {
-    using T = Tile<WZ>;
+    using T = Tile<WZ>;            // box A
+    using TB = Tile<8>;            // box B holds the few lanes that left A: single z-planes, half the LDS
+    constexpr int WZB = 8;
     constexpr bool IDX64 = GENERIC;
     constexpr int NC = (CBET == 4) ? 4 : 1;
-    constexpr int NSLOT = 2 * T::N;                       // box A, box B
+    constexpr int NSLOT = T::N + TB::N;                   // box A, box B
     constexpr int NLDS = NSLOT + (NC - 1) * T::DT;        // + components 1.. of box A (field pass)
     __shared__ double s_val[NLDS];
     const int lane = threadIdx.x;
@@ -335,9 +317,12 @@ __global__ void __launch_bounds__(kWave) k_trace_window(const TraceArgs a)
     bool alive = pre_raynum >= 0;
     if (alive) alive = launch_ray(a, beam, pre_raynum, s);
     const int launched = alive ? 1 : 0;
+    // Lane predicates that steer wave-uniform decisions are kept as 64-bit masks in scalar registers next to
+    // the per-lane flag: `live` = ballot(alive), `hbm` = ballot(homeB); tests on them cost no vector instruction.
+    unsigned long long live = __ballot(alive);
+    if (live == 0ull) return;  // whole bundle culled (cannot happen for a listed patch; cheap guard)
 
     const int nx = a.nx, ny = a.ny, nz = a.nz;
-    const int sY = nz, sX = ny * nz;                      // node-table strides (elements)
     const int sYh = nz + 2, sXh = (ny + 2) * (nz + 2);    // haloed edep strides (:5-7)
     unsigned cell = alive ? (unsigned)((s.ci * ny + s.cj) * nz + s.ck) : 0u;
     double fcx = (double)s.ci, fcy = (double)s.cj, fcz = (double)s.ck;   // the cell as the reference's (double)thisx
@@ -346,12 +331,11 @@ __global__ void __launch_bounds__(kWave) k_trace_window(const TraceArgs a)
 
     double *const tileA = s_val, *const tileB = s_val + T::N;
     Origin oA{0, 0, 0}, oB{0, 0, 0};
-    bool homeB = false;     // per lane: the lane's deposits go to box B
-    bool b_active = false;  // wave-uniform
+    bool homeB = false;            // per lane: the lane's deposits go to box B
+    unsigned long long hbm = 0ull; // its ballot
+    bool b_active = false;         // wave-uniform
     {
-        const unsigned long long m = __ballot(alive);
-        if (m == 0) return;  // whole bundle culled (cannot happen for a listed patch; cheap guard)
-        const int src = ((m >> 27) & 1ull) ? 27 : (__ffsll((long long)m) - 1);
+        const int src = ((live >> 27) & 1ull) ? 27 : (__ffsll((long long)live) - 1);
         for (int z = lane; z < NLDS; z += kWave) s_val[z] = 0.0;
         oA.x = __builtin_amdgcn_readlane(s.ci, src) + 1 - T::W / 2;
         oA.y = __builtin_amdgcn_readlane(s.cj, src) + 1 - T::W / 2;
@@ -362,34 +346,22 @@ __global__ void __launch_bounds__(kWave) k_trace_window(const TraceArgs a)
     // wave-uniform: every live lane was held by a box after the last step and both boxes lie deep inside the grid
     bool deep = false;
 
-    // Software pipeline: the six stencil gathers of a step are issued at the END of the previous step (right
-    // after relocation, together with the kappa gather), so they are in flight during the whole deposit phase.
-    double st_xp = 0, st_xm = 0, st_yp = 0, st_ym = 0, st_zp = 0, st_zm = 0;
-    auto gather_stencil_faces = [&]() {
-        // :212-238 neighbours of the current node as table offsets, one-sided on the faces
-        const int oxm = (s.ci == 0) ? 0 : ((s.ci == nx - 1) ? -2 * sX : -sX);
-        const int oxp = (s.ci == 0) ? 2 * sX : ((s.ci == nx - 1) ? 0 : sX);
-        const int oym = (s.cj == 0) ? 0 : ((s.cj == ny - 1) ? -2 * sY : -sY);
-        const int oyp = (s.cj == 0) ? 2 * sY : ((s.cj == ny - 1) ? 0 : sY);
-        const int ozm = (s.ck == 0) ? 0 : ((s.ck == nz - 1) ? -2 : -1);
-        const int ozp = (s.ck == 0) ? 2 : ((s.ck == nz - 1) ? 0 : 1);
-        st_xp = node_load<IDX64>(a, a.ne3d, cell + oxp);
-        st_xm = node_load<IDX64>(a, a.ne3d, cell + oxm);
-        st_yp = node_load<IDX64>(a, a.ne3d, cell + oyp);
-        st_ym = node_load<IDX64>(a, a.ne3d, cell + oym);
-        st_zp = node_load<IDX64>(a, a.ne3d, cell + ozp);
-        st_zm = node_load<IDX64>(a, a.ne3d, cell + ozm);
+    // Software pipeline: a step's record (cbet_device.h StepRecord: the three kicks and the absorption coefficient
+    // at the ray's node) is gathered as soon as the new node is known; the absorption coefficient is used by the
+    // same step's deposit, the kicks by the NEXT step's move -- so the gather is in flight during the whole
+    // deposit phase.  One aligned 32-byte gather per lane and step.
+    double st_kx = 0, st_ky = 0, st_kz = 0, kap = 0;
+    auto gather_record = [&]() {
+#ifdef CBET_DEBUG_BOUNDS
+        if (!(cell < a.audit_nodes)) { audit_fail(a); return; }
+#endif
+        const double4 r = reinterpret_cast<const double4 *>(a.steprec)[cell];
+        st_kx = r.x;
+        st_ky = r.y;
+        st_kz = r.z;
+        kap = r.w;
     };
-    auto gather_stencil_interior = [&]() {
-        // :254-265 six gathers from the node table, scalar strides added straight into the address
-        st_xp = node_load<IDX64>(a, a.ne3d, cell + sX);
-        st_xm = node_load<IDX64>(a, a.ne3d, cell - sX);
-        st_yp = node_load<IDX64>(a, a.ne3d, cell + sY);
-        st_ym = node_load<IDX64>(a, a.ne3d, cell - sY);
-        st_zp = node_load<IDX64>(a, a.ne3d, cell + 1);
-        st_zm = node_load<IDX64>(a, a.ne3d, cell - 1);
-    };
-    if (alive) gather_stencil_faces();
+    if (alive) gather_record();
     const double *const gk = CBET && a.gain ? a.gain + (long)beam * a.hsize : nullptr;  // this beam's gain grid
     double gained = 0.0;                     // CBET: energy this lane's ray gained
     Deferred dfr;
@@ -397,37 +369,46 @@ __global__ void __launch_bounds__(kWave) k_trace_window(const TraceArgs a)
 
     // lane-dependent corner order (see the weights): which of an axis's two nodes a lane visits first
     const bool flx = (lane & 1) != 0, fly = (lane & 2) != 0, flz = (lane & 8) != 0;
+    const int pfx = flx ? 1 : 0, pfy = fly ? 1 : 0, pfz = flz ? 1 : 0, nfx = 1 - pfx, nfy = 1 - pfy, nfz = 1 - pfz;
 
+    // Per-step values that cross the wave-uniform window logic between a step's two per-lane parts.  Declared
+    // outside the loop on purpose: written and read by live lanes only, a dead lane simply keeps its last value
+    // (re-declaring them per iteration makes the compiler spend ~20 moves per step on defaults for dead lanes).
+    int lx = 0, ly = 0, lz = 0;              // the lane's low corner (haloed)
+    int X0 = 0, X1 = 0, Y0 = 0, Y1 = 0, Z0 = 0, Z1 = 0;
+    double wgt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;   // CBET = 4: the four field quantities a step deposits
+
+    bool slow = true;                        // wave-uniform: this step runs the general (face-aware) forms
+    bool inbox = false;                      // per lane: this step deposits into LDS ...
+    int tile_off = 0;                        // ... into this tile (offset in doubles)
     for (int tt = 0; tt < a.nt; ++tt) {                        // :207
-        if (__ballot(alive) == 0) break;
+        if (live == 0ull) break;
         wc.steps_miss += 1u << 16;
-        double gx = 0.0, gy = 0.0, gz = 0.0;   // position relative to the (new) cell, in cells: xtemp - thisx
-        double kap = 0.0;
-        // ---- move, relocate, gather ---------------------------------------------------------------
-        bool slow = !deep;                     // wave-uniform
-        double fx = 0.0, fy = 0.0, fz = 0.0;
-        int qi = 0, qj = 0, qk = 0;
+        // ---- move (all lanes: a dead lane's state is never read again, so nothing here needs a lane mask and
+        // the wave-uniform decision below is taken outside every divergent region) ------------------------
+        // :268-273 kick then drift (stencil values gathered during the previous step)
+        s.vx -= st_kx;
+        s.vy -= st_ky;
+        s.vz -= st_kz;
+        s.px += s.vx * a.dt;
+        s.py += s.vy * a.dt;
+        s.pz += s.vz * a.dt;
+        // :276-278 position in cell units
+        const double fx = (s.px - a.xmin) * a.inv_dx;
+        const double fy = (s.py - a.ymin) * a.inv_dy;
+        const double fz = (s.pz - a.zmin) * a.inv_dz;
+        // :282-292 nearest-node update, deep-interior form (cbet_relocate.h relocate_deep_interior: exact for
+        // kRelocateDeep <= cell <= n-3 unless the ray moved more than a cell, which sends the wave to the closed form)
+        const double g0x = fx - fcx, g0y = fy - fcy, g0z = fz - fcz;
+        const int qi = s.ci + ((g0x >= kNearTol) ? 1 : 0) - ((g0x < kNearTol - 1.0) ? 1 : 0);
+        const int qj = s.cj + ((g0y >= kNearTol) ? 1 : 0) - ((g0y < kNearTol - 1.0) ? 1 : 0);
+        const int qk = s.ck + ((g0z >= kNearTol) ? 1 : 0) - ((g0z < kNearTol - 1.0) ? 1 : 0);
+        // wave-uniform: this step runs the general (face-aware) forms
+        slow = !deep || ((CBET_BALLOT(!(fabs(g0x) < kFarJump)) | CBET_BALLOT(!(fabs(g0y) < kFarJump)) |
+                                     CBET_BALLOT(!(fabs(g0z) < kFarJump))) & live) != 0ull;
         if (alive) {
-            // :268-273 kick then drift (stencil values gathered during the previous step)
-            s.vx -= a.xconst * (st_xp - st_xm);
-            s.vy -= a.yconst * (st_yp - st_ym);
-            s.vz -= a.zconst * (st_zp - st_zm);
-            s.px += s.vx * a.dt;
-            s.py += s.vy * a.dt;
-            s.pz += s.vz * a.dt;
-            // :276-278 position in cell units
-            fx = (s.px - a.xmin) * a.inv_dx;
-            fy = (s.py - a.ymin) * a.inv_dy;
-            fz = (s.pz - a.zmin) * a.inv_dz;
-            // :282-292 nearest-node update, deep-interior form (exact there; `far` = moved more than a cell)
-            bool far = false;
-            qi = relocate_deep_interior(s.ci, fcx, fx, far);
-            qj = relocate_deep_interior(s.cj, fcy, fy, far);
-            qk = relocate_deep_interior(s.ck, fcz, fz, far);
-            if (!slow) slow = far;             // per lane for now; made wave-uniform below
-        }
-        slow = !deep || any_lane(alive && slow);
-        if (alive) {
+            // ---- relocate, gather -------------------------------------------------------------------
             if (slow) {                        // near a face (or a far jump): closed form with the candidate bounds
                 s.ci = relocate_closed(s.ci, fx, nx);
                 s.cj = relocate_closed(s.cj, fy, ny);
@@ -441,52 +422,46 @@ __global__ void __launch_bounds__(kWave) k_trace_window(const TraceArgs a)
             fcy = (double)s.cj;
             fcz = (double)s.ck;
             cell = (unsigned)(__mul24(__mul24(s.ci, ny) + s.cj, nz) + s.ck);
-            // :296-298 absorption coefficient at the new node, then the NEXT step's stencil
-            if (absorb) kap = node_load<IDX64>(a, a.kap3d, cell);
-            if (slow) gather_stencil_faces(); else gather_stencil_interior();
-            gx = fx - fcx;                     // :319-321 (xtemp - thisx), the - 0.5 follows below
-            gy = fy - fcy;
-            gz = fz - fcz;
-        }
-        if (dfr_pending) {                     // scalar branch: last step's retired planes go to HBM now, behind this step's gathers
-            dfr_pending = false;
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                if (dfr.vx[e] != 0.0) { global_add(a, &edep[dfr.nx[e]], dfr.vx[e]); dfr.vx[e] = 0.0; }
-                if (dfr.vy[e] != 0.0) { global_add(a, &edep[dfr.ny[e]], dfr.vy[e]); dfr.vy[e] = 0.0; }
-            }
-            if (!T::BRICK && dfr.vz != 0.0) { global_add(a, &edep[dfr.nz], dfr.vz); dfr.vz = 0.0; }
-        }
-        // ---- weights (:319-339) ---------------------------------------------------------------------
-        // Each weight is (Fz * Fy) * Fx * inc with F = (1-d) for the ray's own node along that axis and F = d
-        // for the neighbour on the `sign` side (:329-336).  The neighbour lies on the side of the offset's sign
-        // (:338-339), so a lane's two nodes per axis are {low, low + 1}, low = own - 1 iff the offset is negative.
-        // Corner order: the eight (node, weight) pairs are the same whatever order they are enumerated in, and
-        // every product keeps the reference's operand order.  Three lane bits swap which of an axis's two nodes
-        // is visited first, so rays a quarter cell apart that share all 8 target nodes hit different nodes in any
-        // one ds_add_f64 instead of serialising on one address: a patch row is lanes 8r..8r+7 and with 4 rays
-        // per zone the 16 lanes of rows 0-3 x columns 0-3 share a cell; bits 0 and 1 (column) and bit 3 (row)
-        // give those 16 lanes all 8 orders, two lanes each.
-        int lx = 0, ly = 0, lz = 0;            // the lane's low corner (haloed)
-        int X0 = 0, X1 = 0, Y0 = 0, Y1 = 0, Z0 = 0, Z1 = 0;
-        double wgt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;   // CBET = 4: the four field quantities this step deposits
-        if (alive) {
-            const double ox = gx - 0.5, oy = gy - 0.5, oz = gz - 0.5;
+            // :296-298 absorption coefficient at the new node and the NEXT step's kicks
+            gather_record();
+            // ---- weights (:319-339) -----------------------------------------------------------------
+            // Each weight is (Fz * Fy) * Fx * inc with F = (1-d) for the ray's own node along that axis and F = d
+            // for the neighbour on the `sign` side (:329-336).  The neighbour lies on the side of the offset's sign
+            // (:338-339), so a lane's two nodes per axis are {low, low + 1}, low = own - 1 iff the offset is negative.
+            // Corner order: the eight (node, weight) pairs are the same whatever order they are enumerated in, and
+            // every product keeps the reference's operand order.  Three lane bits swap which of an axis's two nodes
+            // is visited first, so rays a quarter cell apart that share all 8 target nodes hit different nodes in any
+            // one ds_add_f64 instead of serialising on one address: a patch row is lanes 8r..8r+7 and with 4 rays
+            // per zone the 16 lanes of rows 0-3 x columns 0-3 share a cell; bits 0 and 1 (column) and bit 3 (row)
+            // give those 16 lanes all 8 orders, two lanes each.
+            const double ox = (fx - fcx) - 0.5, oy = (fy - fcy) - 0.5, oz = (fz - fcz) - 0.5;   // :319-321
             const double dm = 1.0 - fabs(ox), dn = 1.0 - fabs(oy), dl = 1.0 - fabs(oz);
-            const bool ngx = ox < 0, ngy = oy < 0, ngz = oz < 0;
-            lx = s.ci + 1 - (ngx ? 1 : 0);
-            ly = s.cj + 1 - (ngy ? 1 : 0);
-            lz = s.ck + 1 - (ngz ? 1 : 0);
             const double ax_own = 1.0 - dm, ay_own = 1.0 - dn, az_own = 1.0 - dl;
             const double Fx0 = flx ? dm : ax_own, Fx1 = flx ? ax_own : dm;
             const double Fy0 = fly ? dn : ay_own, Fy1 = fly ? ay_own : dn;
             const double Fz0 = flz ? dl : az_own, Fz1 = flz ? az_own : dl;
-            // first-visited node: the own node (the high one iff the offset is negative) unless flipped
-            const bool hx = ngx != flx, hy = ngy != fly, hz = ngz != flz;
-            X0 = lx + (hx ? 1 : 0); X1 = lx + (hx ? 0 : 1);
-            Y0 = ly + (hy ? 1 : 0); Y1 = ly + (hy ? 0 : 1);
-            Z0 = lz + (hz ? 1 : 0); Z1 = lz + (hz ? 0 : 1);
+            // Node indices.  The offsets are xtemp - thisx - 0.5 with |xtemp - thisx| < 0.5001, i.e. negative except in
+            // a 1e-4-wide sliver: when they are negative on every axis of every live lane (a ballot of the three sign
+            // compares: ~98 % of the wave-steps) the low corner is the own node minus one and the first-visited node
+            // depends on the lane's flip bits only.
+            if ((CBET_BALLOT(!(ox < 0)) | CBET_BALLOT(!(oy < 0)) | CBET_BALLOT(!(oz < 0))) == 0ull) {   // scalar branch
+                lx = s.ci;
+                ly = s.cj;
+                lz = s.ck;
+                X0 = s.ci + nfx; X1 = s.ci + pfx;
+                Y0 = s.cj + nfy; Y1 = s.cj + pfy;
+                Z0 = s.ck + nfz; Z1 = s.ck + pfz;
+            } else {
+                const bool ngx = ox < 0, ngy = oy < 0, ngz = oz < 0;
+                lx = s.ci + 1 - (ngx ? 1 : 0);
+                ly = s.cj + 1 - (ngy ? 1 : 0);
+                lz = s.ck + 1 - (ngz ? 1 : 0);
+                // first-visited node: the own node (the high one iff the offset is negative) unless flipped
+                const bool hx = ngx != flx, hy = ngy != fly, hz = ngz != flz;
+                X0 = lx + (hx ? 1 : 0); X1 = lx + (hx ? 0 : 1);
+                Y0 = ly + (hy ? 1 : 0); Y1 = ly + (hy ? 0 : 1);
+                Z0 = lz + (hz ? 1 : 0); Z1 = lz + (hz ? 0 : 1);
+            }
             const double zy00 = Fz0 * Fy0, zy10 = Fz1 * Fy0, zy01 = Fz0 * Fy1, zy11 = Fz1 * Fy1;
             // order (x,y,z) = (0,0,0) (1,0,0) (0,0,1) (1,0,1) (0,1,0) (1,1,0) (0,1,1) (1,1,1) -- :341-348 without the flips
             wgt[0] = zy00 * Fx0;
@@ -530,57 +505,80 @@ __global__ void __launch_bounds__(kWave) k_trace_window(const TraceArgs a)
             }
             ++nsteps;
         }
-        // ---- windows ----------------------------------------------------------------------------------
-        bool inbox;            // the lane deposits into LDS this step ...
-        int tile_off = 0;      // ... into this tile (offset in doubles)
-        {
-            // box A follows the lanes whose home it is
-            const bool memA = alive && !homeB;
-            bool moved = follow_box<WZ, true, NC>(a, tileA, oA, memA, lx, ly, lz, lane, edep, sXh, sYh, wc, dfr, NSLOT, a.comp_stride);
-            dfr_pending = dfr_pending || moved;
-            const bool inA = alive && holds<WZ>(oA, lx, ly, lz);
-            bool inB = false;
-            if (b_active) {  // scalar branch
-                wc.slabs_bsteps += 1u;
-                Deferred unused;
-                moved = follow_box<WZ, false, 1>(a, tileB, oB, alive && homeB, lx, ly, lz, lane, edep, sXh, sYh, wc, unused, 0, 0) || moved;
-                inB = alive && holds<WZ>(oB, lx, ly, lz);
+        if (dfr_pending) {                     // scalar branch: last step's retired planes go to HBM now, behind this step's gathers
+            dfr_pending = false;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (dfr.vx[e] != 0.0) { global_add(a, &edep[dfr.nx[e]], dfr.vx[e]); dfr.vx[e] = 0.0; }
+                if (dfr.vy[e] != 0.0) { global_add(a, &edep[dfr.ny[e]], dfr.vy[e]); dfr.vy[e] = 0.0; }
             }
-            // lanes that fell out of A look for a home in B; an idle B is re-created around the first of them
-            const bool lost = alive && !homeB && !inA;
-            const unsigned long long lost_mask = __builtin_amdgcn_ballot_w64(lost);
-            if (lost_mask != 0ull) {
-                if (!b_active) {
-                    const int src = __ffsll((long long)lost_mask) - 1;
-                    oB.x = __builtin_amdgcn_readlane(lx, src) - (T::W / 2 - 1);
-                    oB.y = __builtin_amdgcn_readlane(ly, src) - (T::W / 2 - 1);
-                    oB.z = __builtin_amdgcn_readlane(lz, src) - 3;
-                    if (T::BRICK) oB.z &= ~7;
-                    b_active = true;  // its tile is all zero: zeroed at start and flushed whenever it empties
-                    moved = true;
-                    inB = alive && holds<WZ>(oB, lx, ly, lz);
-                }
-                homeB = homeB || (lost && inB);
-            }
-            if (b_active) {
-                // a B lane that drifted out of B but back into A goes home
-                if (alive && homeB && !inB && inA) homeB = false;
-                if (!any_lane(alive && homeB)) {
-                    __builtin_amdgcn_wave_barrier();
-                    flush_box<WZ, 1>(a, tileB, oB, lane, edep, sXh, sYh, wc, 0, 0);
-                    b_active = false;
-                    moved = true;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            const bool useB = alive && homeB && inB;
-            inbox = useB || (alive && !homeB && inA);
-            tile_off = useB ? T::N : 0;
-            const bool missed = any_lane(alive && !inbox);
-            if (missed) wc.steps_miss += 1u;
-            if (moved || missed || !deep)
-                deep = !missed && box_deep_inside<WZ>(oA, nx, ny, nz) && (!b_active || box_deep_inside<WZ>(oB, nx, ny, nz));
+            if (!T::BRICK && dfr.vz != 0.0) { global_add(a, &edep[dfr.nz], dfr.vz); dfr.vz = 0.0; }
         }
+        // ---- windows ----------------------------------------------------------------------------------
+        inbox = alive;         // the lane deposits into LDS this step ...
+        tile_off = 0;          // ... into this tile (offset in doubles)
+        {
+            // Common case, decided with three compares: every live lane's eight target nodes lie inside its home box
+            // -- nothing has to move.  (The boxes follow on demand: the step in which a lane leaves is the step in
+            // which its box is shifted, before anything is deposited.)
+            const unsigned long long memA = live & ~hbm, memB = live & hbm;
+            unsigned long long out_core = memA & ~(CBET_BALLOT((unsigned)(lx - oA.x) <= (unsigned)T::S) &
+                                                   CBET_BALLOT((unsigned)(ly - oA.y) <= (unsigned)T::S) &
+                                                   CBET_BALLOT((unsigned)(lz - oA.z) <= (unsigned)T::SZ));
+            if (b_active) {   // scalar branch
+                wc.slabs_bsteps += 1u;
+                out_core |= memB & ~(CBET_BALLOT((unsigned)(lx - oB.x) <= (unsigned)TB::S) &
+                                     CBET_BALLOT((unsigned)(ly - oB.y) <= (unsigned)TB::S) &
+                                     CBET_BALLOT((unsigned)(lz - oB.z) <= (unsigned)TB::SZ));
+                tile_off = homeB ? T::N : 0;
+            }
+            if (out_core != 0ull) {
+                // box A follows the lanes whose home it is
+                bool moved = follow_box<WZ, true, NC>(a, tileA, oA, memA, lx, ly, lz, lane, edep, sXh, sYh, wc, dfr, NSLOT, a.comp_stride);
+                dfr_pending = dfr_pending || moved;
+                const bool inA = alive && holds<WZ>(oA, lx, ly, lz);
+                bool inB = false;
+                if (b_active) {  // scalar branch
+                    Deferred unused;
+                    moved = follow_box<WZB, false, 1>(a, tileB, oB, memB, lx, ly, lz, lane, edep, sXh, sYh, wc, unused, 0, 0) || moved;
+                    inB = alive && holds<WZB>(oB, lx, ly, lz);
+                }
+                // lanes that fell out of A look for a home in B; an idle B is re-created around the first of them
+                const bool lost = alive && !homeB && !inA;
+                const unsigned long long lost_mask = CBET_BALLOT(lost);
+                if (lost_mask != 0ull) {
+                    if (!b_active) {
+                        const int src = __ffsll((long long)lost_mask) - 1;
+                        oB.x = __builtin_amdgcn_readlane(lx, src) - (T::W / 2 - 1);
+                        oB.y = __builtin_amdgcn_readlane(ly, src) - (T::W / 2 - 1);
+                        oB.z = __builtin_amdgcn_readlane(lz, src) - 3;
+                        b_active = true;  // its tile is all zero: zeroed at start and flushed whenever it empties
+                        inB = alive && holds<WZB>(oB, lx, ly, lz);
+                    }
+                    homeB = homeB || (lost && inB);
+                }
+                if (b_active) {
+                    // a B lane that drifted out of B but back into A goes home
+                    if (alive && homeB && !inB && inA) homeB = false;
+                    hbm = CBET_BALLOT(alive && homeB);
+                    if (hbm == 0ull) {
+                        __builtin_amdgcn_wave_barrier();
+                        flush_box<WZB, 1>(a, tileB, oB, lane, edep, sXh, sYh, wc, 0, 0);
+                        b_active = false;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                const bool useB = alive && homeB && inB;
+                inbox = useB || (alive && !homeB && inA);
+                tile_off = useB ? T::N : 0;
+                const bool missed = CBET_BALLOT(alive && !inbox) != 0ull;
+                if (missed) wc.steps_miss += 1u;
+                deep = !missed && box_deep_inside<WZ>(oA, nx, ny, nz) && (!b_active || box_deep_inside<WZB>(oB, nx, ny, nz));
+            } else if (!deep) {
+                deep = box_deep_inside<WZ>(oA, nx, ny, nz) && (!b_active || box_deep_inside<WZB>(oB, nx, ny, nz));
+            }
+        }
+    
         // ---- deposit (:305-311, :341-348) -------------------------------------------------------------
         if (alive) {
             double inc;
@@ -594,22 +592,31 @@ __global__ void __launch_bounds__(kWave) k_trace_window(const TraceArgs a)
 #pragma unroll
             for (int c = 0; c < 8; ++c) wgt[c] = wgt[c] * inc;   // a_c * increment
             if (inbox) {
-                const int x0 = (X0 & 7) * T::XS + tile_off, x1 = (X1 & 7) * T::XS + tile_off;
-                const int y0 = (Y0 & 7) * T::YS, y1 = (Y1 & 7) * T::YS;
-                const int z0 = Z0 & T::ZM, z1 = Z1 & T::ZM;
-                const int s00 = x0 + y0, s10 = x1 + y0, s01 = x0 + y1, s11 = x1 + y1;
-                auto add = [&](int slot, double w) {
-                    if (CBET_AUDIT(a, (unsigned)slot < (unsigned)NSLOT))
-                        __hip_atomic_fetch_add(&s_val[slot], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // slot = (x & 7) * XS + (y & 7) * YS + (z & ZM) with the strides of the lane's tile
+                auto add8 = [&](int xs, int ys, int zm, int off) {
+                    const int x0 = (X0 & 7) * xs + off, x1 = (X1 & 7) * xs + off;
+                    const int y0 = (Y0 & 7) * ys, y1 = (Y1 & 7) * ys;
+                    const int z0 = Z0 & zm, z1 = Z1 & zm;
+                    const int s00 = x0 + y0, s10 = x1 + y0, s01 = x0 + y1, s11 = x1 + y1;
+                    auto add = [&](int slot, double w) {
+                        if (CBET_AUDIT(a, (unsigned)slot < (unsigned)NSLOT))
+                            __hip_atomic_fetch_add(&s_val[slot], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    };
+                    add(s00 + z0, wgt[0]);
+                    add(s10 + z0, wgt[1]);
+                    add(s00 + z1, wgt[2]);
+                    add(s10 + z1, wgt[3]);
+                    add(s01 + z0, wgt[4]);
+                    add(s11 + z0, wgt[5]);
+                    add(s01 + z1, wgt[6]);
+                    add(s11 + z1, wgt[7]);
                 };
-                add(s00 + z0, wgt[0]);
-                add(s10 + z0, wgt[1]);
-                add(s00 + z1, wgt[2]);
-                add(s10 + z1, wgt[3]);
-                add(s01 + z0, wgt[4]);
-                add(s11 + z0, wgt[5]);
-                add(s01 + z1, wgt[6]);
-                add(s11 + z1, wgt[7]);
+                if (!b_active) {   // scalar branch: everything goes to box A, compile-time strides
+                    add8(T::XS, T::YS, T::ZM, 0);
+                } else {
+                    const bool toB = tile_off != 0;
+                    add8(toB ? TB::XS : T::XS, toB ? TB::YS : T::YS, toB ? TB::ZM : T::ZM, tile_off);
+                }
             } else {
                 const int nX0 = __mul24(X0, sXh), nX1 = __mul24(X1, sXh), nY0 = __mul24(Y0, sYh), nY1 = __mul24(Y1, sYh);
                 global_add(a, &edep[nX0 + nY0 + Z0], wgt[0]);
@@ -642,17 +649,23 @@ __global__ void __launch_bounds__(kWave) k_trace_window(const TraceArgs a)
                     wc.n_atomics += 3;
                 }
             }
-            // ---- termination (:351-356) ----------------------------------------------------------------
-            if (s.uray <= s.ustop) alive = false;
         }
-        __builtin_amdgcn_wave_barrier();
-        // The six exit planes are compared only when the wave is not deep inside the grid: a lane held by a
-        // deep box is more than two cells from every face, far beyond the half cell of :352-354.
-        if (slow || !deep) {
+        // ---- termination (:351-356) --------------------------------------------------------------------
+        // The six exit planes are compared only when the wave is not deep inside the grid: a lane held by a deep
+        // box is more than two cells from every face, far beyond the half cell of :352-354.  Ballots of plain
+        // compares over all lanes, masked with `live` on the scalar unit.
+        unsigned long long died = CBET_BALLOT(s.uray <= s.ustop);
+        if (slow || !deep) {   // scalar branch
             const double *b = a.bounds;  // {xlo, xhi, ylo, yhi, zlo, zhi}
-            if (alive && (s.px < b[0] || s.px > b[1] || s.py < b[2] || s.py > b[3] || s.pz < b[4] || s.pz > b[5]))
-                alive = false;
+            died |= CBET_BALLOT(s.px < b[0]) | CBET_BALLOT(s.px > b[1]) | CBET_BALLOT(s.py < b[2]) |
+                    CBET_BALLOT(s.py > b[3]) | CBET_BALLOT(s.pz < b[4]) | CBET_BALLOT(s.pz > b[5]);
+            alive = alive && !(s.uray <= s.ustop || s.px < b[0] || s.px > b[1] || s.py < b[2] || s.py > b[3] || s.pz < b[4] || s.pz > b[5]);
+        } else {
+            alive = alive && !(s.uray <= s.ustop);
         }
+        live &= ~died;
+        hbm &= live;
+        __builtin_amdgcn_wave_barrier();
     }
 
     // whatever is still in flight or in LDS
@@ -664,7 +677,7 @@ __global__ void __launch_bounds__(kWave) k_trace_window(const TraceArgs a)
     if (!T::BRICK && dfr.vz != 0.0) global_add(a, &edep[dfr.nz], dfr.vz);
     __syncthreads();
     flush_box<WZ, NC>(a, tileA, oA, lane, edep, sXh, sYh, wc, NSLOT, a.comp_stride);
-    if (b_active) flush_box<WZ, 1>(a, tileB, oB, lane, edep, sXh, sYh, wc, 0, 0);
+    if (b_active) flush_box<WZB, 1>(a, tileB, oB, lane, edep, sXh, sYh, wc, 0, 0);
 
     if (CBET && a.beam_gain) {  // one fp64 atomic per wave
         double t = gained;
@@ -694,9 +707,9 @@ hipError_t launch_trace_window(const TraceArgs &a, bool force_idx64, hipStream_t
     const long waves = (a.total_bundles - a.shard_index + a.shard_count - 1) / a.shard_count;
     if (waves <= 0) return hipSuccess;
     const dim3 grid((unsigned)waves), block(kWave);
-    // 32-bit byte offsets into the node tables -- and, with the CBET hooks, into a beam's haloed gain grid
-    const unsigned long long table_bytes = 8ull * (a.gain ? (unsigned long long)a.hsize : (unsigned long long)a.nx * a.ny * a.nz);
-    const bool generic = force_idx64 || table_bytes >= (1ull << 32) || a.absorption != 1;
+    // the step records are addressed with 64 bits always; GENERIC is needed for bookkeeping mode and, with the CBET
+    // hooks, for gain grids of >= 2^32 bytes (32-bit byte offsets otherwise)
+    const bool generic = force_idx64 || (a.gain && 8ull * (unsigned long long)a.hsize >= (1ull << 32)) || a.absorption != 1;
     if (a.quantity != 0) {  // the fused four-component field pass (single z-planes: four tiles per wave must fit)
         if (generic) hipLaunchKernelGGL((k_trace_window<8, true, 4>), grid, block, 0, stream, a);
         else hipLaunchKernelGGL((k_trace_window<8, false, 4>), grid, block, 0, stream, a);
