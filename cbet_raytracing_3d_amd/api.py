@@ -46,6 +46,7 @@ class Params(C.Structure):
         ("shard_index", C.c_int), ("shard_count", C.c_int),
         ("kernel_variant", C.c_int), ("force_wide_index", C.c_int),
         ("per_beam_grids", C.c_int), ("patch_order", C.c_int),
+        ("grid_beam0", C.c_int), ("grid_beams", C.c_int), ("order_phases", C.c_int),
     ]
 
     def copy(self, **overrides):
@@ -107,11 +108,12 @@ EXPORTS = [
     "cbet_live_ray_list", "cbet_omega60_beam_norm", "cbet_host_power_table", "cbet_host_beam_trig", "cbet_read_profile",
     "cbet_safeGPUAlloc", "cbet_moveToAndFromGPU", "cbet_gpuFree",
     "cbet_context_create", "cbet_context_destroy", "cbet_context_counters", "cbet_context_tables",
-    "cbet_launch_ray_XYZ", "cbet_tabulate_plasma", "cbet_trace_nodes", "cbet_ray_tracing",
+    "cbet_launch_ray_XYZ", "cbet_tabulate_plasma", "cbet_trace_nodes", "cbet_prepare_step_records", "cbet_ray_tracing",
     "cbet_write_text", "cbet_edep_average", "cbet_edep_average_device", "cbet_node_coordinates", "cbet_write_npy",
     "cbet_debug_bounds_violations",
     "cbet_gain_params_default", "cbet_gain_constants", "cbet_trace_cbet", "cbet_gain_field",
-    "cbet_cbet_workspace_bytes", "cbet_cbet_solve", "cbet_gain_field_slab",
+    "cbet_cbet_workspace_bytes", "cbet_cbet_solve", "cbet_gain_field_slab", "cbet_gain_field_packed",
+    "cbet_cbet_slab_workspace_bytes",
 ]
 
 _lib = None
@@ -154,6 +156,7 @@ def lib():
     L.cbet_launch_ray_XYZ.argtypes = [C.c_int, C.c_uint, vp, vp, vp, vp, vp, vp, vp, vp,
                                       C.c_double, C.c_double, C.c_double, C.POINTER(Params), vp, vp]
     L.cbet_tabulate_plasma.argtypes = [vp, C.POINTER(Params), vp, vp, vp, vp]
+    L.cbet_prepare_step_records.argtypes = [vp, C.POINTER(Params), vp, vp, C.c_double, C.c_double, C.c_double, vp]
     L.cbet_trace_nodes.argtypes = [C.c_int, C.c_uint, vp, vp, vp, vp, vp, vp, vp,
                                    C.c_double, C.c_double, C.c_double, C.POINTER(Params), vp, vp]
     L.cbet_ray_tracing.argtypes = [dp, dp, dp, dp, C.POINTER(Params), dp, ip, C.c_int, dp,
@@ -172,6 +175,9 @@ def lib():
                                   C.c_double, C.c_double, C.c_double, C.POINTER(Params), C.POINTER(GainParams), vp, vp]
     L.cbet_gain_field.argtypes = [vp, vp, vp, vp, vp, C.POINTER(Params), C.POINTER(GainParams), vp, vp]
     L.cbet_gain_field_slab.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.POINTER(Params), C.POINTER(GainParams), vp, vp]
+    L.cbet_gain_field_packed.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.POINTER(Params), C.POINTER(GainParams), vp, vp]
+    L.cbet_cbet_slab_workspace_bytes.argtypes = [C.POINTER(Params), C.c_int, C.c_int]
+    L.cbet_cbet_slab_workspace_bytes.restype = C.c_size_t
     L.cbet_cbet_workspace_bytes.argtypes = [C.POINTER(Params)]
     L.cbet_cbet_workspace_bytes.restype = C.c_size_t
     L.cbet_cbet_solve.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(Params), C.POINTER(GainParams), vp, vp, vp,
@@ -242,8 +248,14 @@ def shard_items(p, nbeams_local, shard_index, shard_count):
     live = live_ray_list(p)
     bpb = (len(live) + 63) // 64
     beams, ids = [], []
+    phases = p.order_phases if p.order_phases >= 1 else (2 if shard_count > 1 and p.patch_order != 0 else 1)
+    split = max(1, bpb // 3) if phases == 2 and bpb >= 3 else bpb      # cbet_phase_split
+    first = nbeams_local * split
     for g in range(shard_index, nbeams_local * bpb, max(1, shard_count)):
-        b, k = g // bpb, g % bpb
+        if g < first:
+            b, k = g // split, g % split
+        else:
+            b, k = (g - first) // (bpb - split), split + (g - first) % (bpb - split)
         chunk = live[64 * k: 64 * k + 64]
         chunk = chunk[chunk >= 0]
         beams.append(np.full(len(chunk), b, dtype=np.int32))
@@ -353,6 +365,12 @@ def tabulate_plasma(ctx, params, te_data_g, r_data_g, ne_data_g, stream=None):
                                       _addr(r_data_g), _addr(ne_data_g), _addr(stream)))
 
 
+def prepare_step_records(ctx, params, ne3d, kappa3d, xconst, yconst, zconst, stream=None):
+    """Build the default kernel's per-node step records now instead of inside the next launch (see the header)."""
+    _check(lib().cbet_prepare_step_records(ctx.handle, C.byref(params), _addr(ne3d), _addr(kappa3d), xconst, yconst,
+                                           zconst, _addr(stream)))
+
+
 def trace_nodes(b, nindices, ne3d, kappa3d, edep, bbeam_norm, beam_norm, pow_r, phase_r, xconst,
                 yconst, zconst, params, ctx, stream=None):
     _check(lib().cbet_trace_nodes(
@@ -388,6 +406,16 @@ def trace_cbet(b, nindices, ne3d, kappa3d, gain, quantity, out, beam_gain, bbeam
 def gain_field(fields, ne3d, gain, scratch, change, params, gain_params, ctx, stream=None):
     _check(lib().cbet_gain_field(_addr(fields), _addr(ne3d), _addr(gain), _addr(scratch), _addr(change),
                                  C.byref(params), C.byref(gain_params), ctx.handle, _addr(stream)))
+
+
+def gain_field_packed(fields, ne3d, gain, scratch, change, hx_lo, hx_hi, params, gain_params, ctx, stream=None):
+    """cbet_gain_field_slab on slab-packed arrays (planes [hx_lo, hx_hi) of every beam only)."""
+    _check(lib().cbet_gain_field_packed(_addr(fields), _addr(ne3d), _addr(gain), _addr(scratch), _addr(change), hx_lo, hx_hi,
+                                        C.byref(params), C.byref(gain_params), ctx.handle, _addr(stream)))
+
+
+def cbet_slab_workspace_bytes(params, world_size, rank):
+    return int(lib().cbet_cbet_slab_workspace_bytes(C.byref(params), world_size, rank))
 
 
 def gain_field_slab(fields, ne3d, gain, scratch, change, hx_lo, hx_hi, params, gain_params, ctx, stream=None):

@@ -121,6 +121,13 @@ static std::vector<double> launch_axis(int count, int denom_count, double half_c
     return t;
 }
 
+// patches of a beam that count as "long" in the two-phase order (api.shard_items mirrors this)
+static int phase_split_of(int bundles_per_beam)
+{
+    const int s = bundles_per_beam / 3;
+    return s < 1 ? bundles_per_beam : s;
+}
+
 static unsigned morton2(unsigned x, unsigned y)
 {
     auto spread = [](unsigned v) {
@@ -204,7 +211,11 @@ struct cbet_context {
     cbet_params p{};
     cbet_derived d{};
     double *ne3d = nullptr, *kap3d = nullptr;
-    StepRecord *steprec = nullptr;      // per-node step records of the LDS_WINDOW kernel, rebuilt by every launch that uses them
+    StepRecord *steprec = nullptr;      // per-node step records of the LDS_WINDOW kernel (cbet_device.h)
+    // what the records were built from: valid while the context's own tables are unchanged (tables_version)
+    unsigned long long tables_version = 0, rec_version = ~0ull;
+    const double *rec_ne3d = nullptr, *rec_kap3d = nullptr;
+    double rec_const[3] = {0, 0, 0};
     double *xlaunch = nullptr, *ylaunch = nullptr;
     double *bounds = nullptr;  // {xlo,xhi,ylo,yhi,zlo,zhi}
     int *live = nullptr;
@@ -236,6 +247,7 @@ int cbet_params_default(cbet_params *p, int n)
     p->shard_count = 1;
     p->kernel_variant = CBET_KERNEL_DEFAULT;
     p->patch_order = 1;
+    p->order_phases = -1;
     return CBET_OK;
 }
 
@@ -496,7 +508,42 @@ int cbet_tabulate_plasma(cbet_context *ctx, const cbet_params *p, const double *
     t.r = r_data_g; t.ne = ne_data_g; t.te = te_data_g;
     t.ne3d = ctx->ne3d; t.kap3d = ctx->kap3d;
     CBET_HIP(launch_tabulate(t, (hipStream_t)stream));
+    ++ctx->tables_version;   // step records built from the old tables are stale
     return CBET_OK;
+}
+
+// Build the per-node step records (cbet_device.h StepRecord) the LDS_WINDOW kernel gathers from: ne3d / kappa3d
+// NULL = the context's own tables.  Records built from the context's tables stay valid until the next
+// cbet_tabulate_plasma; records built from caller-owned tables are rebuilt by every launch (their contents may
+// have changed).
+static int step_records(cbet_context *ctx, const cbet_params *p, const double *ne3d, const double *kappa3d,
+                        double xconst, double yconst, double zconst, void *stream, bool force)
+{
+    const bool own = !ne3d && !kappa3d;
+    const double *ne = ne3d ? ne3d : ctx->ne3d, *kap = kappa3d ? kappa3d : ctx->kap3d;
+    if (!force && own && ctx->rec_version == ctx->tables_version && ctx->rec_ne3d == ne && ctx->rec_kap3d == kap &&
+        ctx->rec_const[0] == xconst && ctx->rec_const[1] == yconst && ctx->rec_const[2] == zconst)
+        return CBET_OK;
+    StepTableArgs t{};
+    t.nx = p->nx; t.ny = p->ny; t.nz = p->nz;
+    t.xconst = xconst; t.yconst = yconst; t.zconst = zconst;
+    t.ne3d = ne; t.kap3d = kap; t.rec = ctx->steprec;
+    CBET_HIP(launch_step_table(t, (hipStream_t)stream));
+    ctx->rec_version = own ? ctx->tables_version : ~0ull;
+    ctx->rec_ne3d = ne; ctx->rec_kap3d = kap;
+    ctx->rec_const[0] = xconst; ctx->rec_const[1] = yconst; ctx->rec_const[2] = zconst;
+    return CBET_OK;
+}
+
+int cbet_prepare_step_records(cbet_context *ctx, const cbet_params *p, const double *ne3d, const double *kappa3d,
+                              double xconst, double yconst, double zconst, void *stream)
+{
+    if (!ctx) return fail(CBET_EINVAL, "NULL context");
+    if (int rc = validate(p)) return rc;
+    if (int rc = check_geometry(ctx, p)) return rc;
+    DeviceGuard guard;
+    CBET_HIP(hipSetDevice(ctx->gpu));
+    return step_records(ctx, p, ne3d, kappa3d, xconst, yconst, zconst, stream, true);
 }
 
 // CBET hooks of a trace launch (all zero: the reference path).
@@ -565,25 +612,32 @@ static int trace_impl(int b, unsigned nindices, const double *ne3d, const double
     a.total_bundles = (long)a.nbeams_local * a.bundles_per_beam;
     a.shard_index = p->shard_count > 1 ? p->shard_index : 0;
     a.shard_count = p->shard_count > 1 ? p->shard_count : 1;
+    {   // work-item order (cbet_params.order_phases)
+        const int phases = p->order_phases < 1 ? (a.shard_count > 1 && p->patch_order != 0 ? 2 : 1) : p->order_phases;
+        if (phases > 2) return fail(CBET_EINVAL, "order_phases must be -1 (auto), 1 or 2");
+        a.phase_split = phases == 2 ? phase_split_of(a.bundles_per_beam) : a.bundles_per_beam;
+    }
     a.ne3d = ne3d ? ne3d : ctx->ne3d;
     a.kap3d = kappa3d ? kappa3d : ctx->kap3d;
     a.beam_norm = beam_norm; a.bbeam_norm = bbeam_norm; a.pow_r = pow_r; a.phase_r = phase_r;
     a.edep = edep;
     a.grid_stride = (p->per_beam_grids || hooks.quantity != 0) ? d.edep_size : 0;  // field passes are always beam-resolved
-    a.comp_stride = (long)p->nbeams * d.edep_size;
+    // beam-resolved arrays may hold only the grids of beams [grid_beam0, grid_beam0 + grid_beams)
+    const int gb_n = p->grid_beams > 0 ? p->grid_beams : p->nbeams, gb_0 = p->grid_beams > 0 ? p->grid_beam0 : 0;
+    if ((a.grid_stride != 0 || hooks.gain) && (beam_lo < gb_0 || beam_hi > gb_0 + gb_n))
+        return fail(CBET_EINVAL, "beams [%d,%d) are not all inside the beam-resolved arrays' range [%d,%d)", beam_lo, beam_hi,
+                    gb_0, gb_0 + gb_n);
+    a.grid_beam0 = gb_0;
+    a.comp_stride = (long)gb_n * d.edep_size;
     a.counters = ctx->counters;
     a.gain = hooks.gain; a.hsize = d.edep_size; a.quantity = hooks.quantity;
     a.max_exponent = hooks.max_exponent; a.beam_gain = hooks.beam_gain;
     DeviceGuard guard;
     CBET_HIP(hipSetDevice(ctx->gpu));
     if (variant == CBET_KERNEL_LDS_WINDOW) {
-        // the shipped kernel reads one 32-byte record per node; built here because only the launch knows both
-        // the tables (possibly the caller's) and the gradient constants (0.15 ms at 256^3, part of every pass)
-        StepTableArgs t{};
-        t.nx = p->nx; t.ny = p->ny; t.nz = p->nz;
-        t.xconst = xconst; t.yconst = yconst; t.zconst = zconst;
-        t.ne3d = a.ne3d; t.kap3d = a.kap3d; t.rec = ctx->steprec;
-        CBET_HIP(launch_step_table(t, (hipStream_t)stream));
+        // the shipped kernel gathers one 32-byte record per node; built here (unless still valid) because only
+        // the launch knows both the tables -- possibly the caller's -- and the gradient constants
+        if (int rc = step_records(ctx, p, ne3d, kappa3d, xconst, yconst, zconst, stream, false)) return rc;
         a.steprec = ctx->steprec;
     }
     CBET_HIP(launch_trace(a, variant, p->force_wide_index != 0, (hipStream_t)stream));
@@ -720,9 +774,38 @@ int cbet_gain_field(double *fields, const double *ne3d, double *gain, double *sc
     return cbet_gain_field_slab(fields, ne3d, gain, scratch, change, 0, p ? p->nx + 2 : 0, p, g, ctx, stream);
 }
 
+static int gain_field_impl(double *fields, const double *ne3d, double *gain, double *scratch, double *change,
+                           int hx_lo, int hx_hi, bool packed, const cbet_params *p, const cbet_gain_params *g,
+                           cbet_context *ctx, void *stream);
+
 int cbet_gain_field_slab(double *fields, const double *ne3d, double *gain, double *scratch, double *change,
                          int hx_lo, int hx_hi, const cbet_params *p, const cbet_gain_params *g,
                          cbet_context *ctx, void *stream)
+{
+    return gain_field_impl(fields, ne3d, gain, scratch, change, hx_lo, hx_hi, false, p, g, ctx, stream);
+}
+
+int cbet_gain_field_packed(double *fields, const double *ne3d, double *gain, double *scratch, double *change,
+                           int hx_lo, int hx_hi, const cbet_params *p, const cbet_gain_params *g,
+                           cbet_context *ctx, void *stream)
+{
+    return gain_field_impl(fields, ne3d, gain, scratch, change, hx_lo, hx_hi, true, p, g, ctx, stream);
+}
+
+size_t cbet_cbet_slab_workspace_bytes(const cbet_params *p, int world_size, int rank)
+{
+    if (!p || validate(p) != CBET_OK || world_size < 1 || rank < 0 || rank >= world_size) return 0;
+    const size_t plane = (size_t)(p->ny + 2) * (p->nz + 2), hsize = (size_t)(p->nx + 2) * plane, nb = (size_t)p->nbeams;
+    // contiguous near-equal parts, as tracer._parts
+    const size_t own_beams = ((size_t)(rank + 1) * nb) / world_size - ((size_t)rank * nb) / world_size;
+    const size_t own_planes = ((size_t)(rank + 1) * (p->nx + 2)) / world_size - ((size_t)rank * (p->nx + 2)) / world_size;
+    // own beams over the whole grid: 4 field components + gain; all beams over the own slab: 4 components + gain + scratch
+    return (5 * own_beams * hsize + 6 * nb * own_planes * plane + 2 + CBET_MAX_CBET_BEAMS) * sizeof(double);
+}
+
+static int gain_field_impl(double *fields, const double *ne3d, double *gain, double *scratch, double *change,
+                           int hx_lo, int hx_hi, bool packed, const cbet_params *p, const cbet_gain_params *g,
+                           cbet_context *ctx, void *stream)
 {
     if (!ctx) return fail(CBET_EINVAL, "NULL context");
     if (int rc = validate(p)) return rc;
@@ -743,6 +826,10 @@ int cbet_gain_field_slab(double *fields, const double *ne3d, double *gain, doubl
     a.relax = g->relax;
     a.fields = fields; a.ne3d = ne3d ? ne3d : ctx->ne3d; a.gain = gain; a.scratch = scratch; a.change = change;
     a.hx_lo = hx_lo; a.hx_hi = hx_hi;
+    const long plane = (long)(p->ny + 2) * (p->nz + 2);
+    a.store0 = packed ? (long)hx_lo * plane : 0;
+    a.bstride = packed ? (long)(hx_hi - hx_lo) * plane : d.edep_size;
+    if (hx_hi == hx_lo) return CBET_OK;   // an empty slab (more ranks than planes)
     DeviceGuard guard;
     CBET_HIP(hipSetDevice(ctx->gpu));
     CBET_HIP(launch_gain_field(a, (hipStream_t)stream));

@@ -76,6 +76,7 @@ struct TraceArgs {
     int beam_lo, nbeams_local, bundles_per_beam;
     long total_bundles;
     int shard_index, shard_count;
+    int phase_split;                        // work-item order: patches [0, phase_split) of every beam first, then the rest (bundles_per_beam: one phase)
     // tables
     const double *ne3d, *kap3d;
     const StepRecord *steprec;              // LDS_WINDOW kernel: per-node step records built from the two tables
@@ -88,7 +89,8 @@ struct TraceArgs {
     const double *audit_lo, *audit_hi;      // the grid range a launch may add into
     unsigned long long audit_nodes, audit_hsize;  // entries of a node table / of a beam's haloed gain grid
     // CBET extension (no reference counterpart).  All zero / NULL = the reference path.
-    const double *gain;                     // [nbeams][(n+2)^3] gain coefficient on the deposit grid, 1/cm
+    int grid_beam0;                         // beam whose grid comes first in a beam-resolved `edep` / in `gain` (cbet_params.grid_beam0)
+    const double *gain;                     // [grid beams][(n+2)^3] gain coefficient on the deposit grid, 1/cm
     long hsize;                             // (nx+2)(ny+2)(nz+2)
     int quantity;                           // 0: deposit the absorbed energy; 1: the four field components (fused field pass)
     long comp_stride;                       // field pass: doubles between the component arrays (nbeams * hsize)
@@ -110,6 +112,8 @@ struct GainArgs {
     double *scratch;                        // [nbeams][hsize] work array of the symmetric kernel, or NULL (ordered kernel)
     double *change;                         // device {sum |new-old|, sum |new|} accumulators, or NULL
     int hx_lo, hx_hi;                       // planes [hx_lo, hx_hi) of the haloed grid to update (a rank's slab; 0 .. nx+2 = all)
+    // storage of fields / gain / scratch: entry of cell h of beam b at [b * bstride + h - store0] (+ component * nbeams * bstride)
+    long store0, bstride;                   // whole-grid arrays: 0, hsize; slab-packed arrays: hx_lo * (ny+2)(nz+2), slab entries
 };
 
 hipError_t launch_tabulate(const TabulateArgs &a, hipStream_t stream);

@@ -55,7 +55,7 @@ __device__ __forceinline__ CellState cell_state(const GainArgs &a, long h)
 __global__ void __launch_bounds__(256) k_gain_field(const GainArgs a)
 {
     const int HY = a.ny + 2, HZ = a.nz + 2;
-    const long hsize = (long)(a.nx + 2) * HY * HZ;
+    const long hsize = a.bstride;                 // entries stored per beam (the whole haloed grid, or one x-slab of it)
     const long total = hsize * a.nbeams;
     const int bx0 = a.hx_lo >> 1, bx = ((a.hx_hi + 1) >> 1) - bx0;   // brick columns touching the slab [hx_lo, hx_hi)
     const int by = (HY + 3) / 4, bz = (HZ + 7) / 8;
@@ -71,8 +71,9 @@ __global__ void __launch_bounds__(256) k_gain_field(const GainArgs a)
         const int iby = (int)(t % by), ibx = bx0 + (int)(t / by);
         const int hi = 2 * ibx + (lane >> 5), hj = 4 * iby + ((lane >> 3) & 3), hk = 8 * ibz + (lane & 7);
         const bool valid = hi >= a.hx_lo && hi < a.hx_hi && hj < HY && hk < HZ;
-        const long h = valid ? ((long)hi * HY + hj) * HZ + hk : 0;
-        double *fI = a.fields + h, *fx = fI + total, *fy = fx + total, *fz = fy + total;
+        const long h = valid ? ((long)hi * HY + hj) * HZ + hk : a.store0;
+        const long hs = h - a.store0;               // index into the (possibly slab-packed) arrays
+        double *fI = a.fields + hs, *fx = fI + total, *fy = fx + total, *fz = fy + total;
         const CellState c = cell_state(a, h);
         const double kmag = a.k0 * c.rt;
         const double ds_node = (kC * c.rt) * a.dt;  // group speed x dt: energy x length -> intensity
@@ -122,7 +123,7 @@ __global__ void __launch_bounds__(256) k_gain_field(const GainArgs a)
                 raw = acc;
             }
             if (valid) {
-                double *gp = a.gain + oi + h;
+                double *gp = a.gain + oi + hs;
                 const double old = *gp;
                 const double nw = old + a.relax * (raw - old);
                 if (nw != old) *gp = nw;
@@ -172,7 +173,7 @@ __device__ __forceinline__ double pair_gain(const BeamAtCell &bi, const BeamAtCe
 __global__ void __launch_bounds__(256) k_gain_field_sym(const GainArgs a)
 {
     const int HY = a.ny + 2, HZ = a.nz + 2;
-    const long hsize = (long)(a.nx + 2) * HY * HZ;
+    const long hsize = a.bstride;                 // entries stored per beam (the whole haloed grid, or one x-slab of it)
     const long total = hsize * a.nbeams;
     const int bx0 = a.hx_lo >> 1, bx = ((a.hx_hi + 1) >> 1) - bx0;   // brick columns touching the slab [hx_lo, hx_hi)
     const int by = (HY + 3) / 4, bz = (HZ + 7) / 8;
@@ -188,9 +189,10 @@ __global__ void __launch_bounds__(256) k_gain_field_sym(const GainArgs a)
         const int iby = (int)(t % by), ibx = bx0 + (int)(t / by);
         const int hi = 2 * ibx + (lane >> 5), hj = 4 * iby + ((lane >> 3) & 3), hk = 8 * ibz + (lane & 7);
         const bool valid = hi >= a.hx_lo && hi < a.hx_hi && hj < HY && hk < HZ;
-        const long h = valid ? ((long)hi * HY + hj) * HZ + hk : 0;
-        double *fI = a.fields + h, *fx = fI + total, *fy = fx + total, *fz = fy + total;
-        double *raw = a.scratch + h;
+        const long h = valid ? ((long)hi * HY + hj) * HZ + hk : a.store0;
+        const long hs = h - a.store0;               // index into the (possibly slab-packed) arrays
+        double *fI = a.fields + hs, *fx = fI + total, *fy = fx + total, *fz = fy + total;
+        double *raw = a.scratch + hs;
         const CellState c = cell_state(a, h);
         const double kmag = a.k0 * c.rt;
         const double ds_node = (kC * c.rt) * a.dt;
@@ -274,7 +276,7 @@ __global__ void __launch_bounds__(256) k_gain_field_sym(const GainArgs a)
                     // a beam that is absent from THIS cell has K = 0 (its sums above came from whatever its
                     // entry held); its intensity was masked to zero, so it gave nothing to the others
                     const double r = A[s].I > 0.0 ? raw[o] + KA[s] : 0.0;
-                    double *gp = a.gain + o + h;
+                    double *gp = a.gain + o + hs;
                     const double old = *gp;
                     const double nw = old + a.relax * (r - old);
                     if (nw != old) *gp = nw;
@@ -287,7 +289,7 @@ __global__ void __launch_bounds__(256) k_gain_field_sym(const GainArgs a)
             while (rest != 0ull) {
                 const int b = __ffsll((long long)rest) - 1;
                 rest &= rest - 1;
-                double *gp = a.gain + (long)b * hsize + h;
+                double *gp = a.gain + (long)b * hsize + hs;
                 const double old = *gp;
                 const double nw = old + a.relax * (0.0 - old);
                 if (nw != old) *gp = nw;

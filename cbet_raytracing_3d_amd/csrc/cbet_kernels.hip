@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(kWave) k_trace_simple(const TraceArgs a)
     const int lane = threadIdx.x;
     int beam, patch;
     if (!work_item(a, blockIdx.x, beam, patch)) return;
-    double *const edep = a.edep + (long)beam * a.grid_stride;
+    double *const edep = a.edep + (long)(beam - a.grid_beam0) * a.grid_stride;
     const bool absorb = a.absorption == 1;
 
     Ray s;
@@ -387,7 +387,7 @@ hipError_t launch_trace(const TraceArgs &a0, int variant, bool force_idx64, hipS
     {   // the ranges the audited accesses are checked against
         const long cells = (long)(a.nx + 2) * (a.ny + 2) * (a.nz + 2);
         a.audit_lo = a.edep;
-        a.audit_hi = a.edep + (a.grid_stride ? a.grid_stride * (long)(a.beam_lo + a.nbeams_local) : cells);
+        a.audit_hi = a.edep + (a.grid_stride ? a.grid_stride * (long)(a.beam_lo - a.grid_beam0 + a.nbeams_local) : cells);
         if (a.quantity != 0) a.audit_hi = a.edep + 4 * a.comp_stride;   // the field pass writes four component arrays
         a.audit_nodes = (unsigned long long)a.nx * a.ny * a.nz;
         a.audit_hsize = (unsigned long long)a.hsize;

@@ -145,11 +145,7 @@ __device__ __forceinline__ void global_add(const TraceArgs &a, double *p, double
     (void)a;
 #endif
     // native global_atomic_add_f64, no CAS loop (checked in the ISA)
-#ifndef CBET_EXP_NO_ATOMICS   // TEMPORARY timing-only experiment
     unsafeAtomicAdd(p, v);
-#else
-    (void)p; (void)v;
-#endif
 }
 
 __device__ __forceinline__ int wave_sum(int v)
@@ -212,16 +208,28 @@ __device__ __forceinline__ double phi_det(double x)
     return p;
 }
 
-// The work item of workgroup `w` of a launch: which (beam, patch) bundle.  Beam-major: consecutive
-// workgroups are neighbouring patches of one beam and share node-table lines in L2/MALL (a globally
-// longest-first order and a patch-major order were measured 9-17 % slower).  Interleaved
-// sharding over (beam, bundle) pairs: item g belongs to shard g % shard_count.
+// The work item of workgroup `w` of a launch: which (beam, patch) bundle.  Beam-major: consecutive workgroups
+// are neighbouring patches of one beam and share table lines in L2/MALL.  A beam's patches are listed longest
+// rays first; with phase_split < bundles_per_beam the launch runs in two phases -- every beam's first
+// phase_split patches (the long bundles), beam by beam, then every beam's remaining (short) ones -- so that a
+// SHORT launch (one rank's share of a sharded pass) ends on short bundles instead of waiting ~a bundle lifetime
+// for the last beam's long ones; a full-size launch keeps one phase (two cost it ~10 % in cache locality,
+// DESIGN.md 6.1).  Interleaved sharding: item g belongs to shard g % shard_count.
 __device__ __forceinline__ bool work_item(const TraceArgs &a, long w, int &beam, int &patch)
 {
     const long g = a.shard_index + (long)a.shard_count * w;
     if (g >= a.total_bundles) return false;  // wave-uniform
-    const int beam_local = (int)(g / a.bundles_per_beam);
-    patch = (int)(g - (long)beam_local * a.bundles_per_beam);
+    const long first = (long)a.nbeams_local * a.phase_split;   // items of the first phase
+    int beam_local;
+    if (g < first) {
+        beam_local = (int)(g / a.phase_split);
+        patch = (int)(g - (long)beam_local * a.phase_split);
+    } else {
+        const int rest = a.bundles_per_beam - a.phase_split;
+        const long h = g - first;
+        beam_local = (int)(h / rest);
+        patch = a.phase_split + (int)(h - (long)beam_local * rest);
+    }
     beam = a.beam_lo + beam_local;
     return true;
 }

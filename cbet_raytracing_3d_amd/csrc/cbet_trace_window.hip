@@ -284,15 +284,12 @@ __device__ __forceinline__ bool box_deep_inside(const Origin &o, int nx, int ny,
 // The kernel.
 // ---------------------------------------------------------------------------------------------
 #define CBET_BALLOT(cond) __builtin_amdgcn_ballot_w64(cond)
-#ifndef CBET_MIN_WAVES
-#define CBET_MIN_WAVES 1
-#endif
 
 constexpr double kNearTol = 0.5001;   // launch_ray_XZ.cu:132, the nearest-node tolerance
 constexpr double kFarJump = 1.4998;   // relocate_deep_interior's validity bound on |f - cell|
 
 template <int WZ, bool GENERIC, int CBET>
-__global__ void __launch_bounds__(kWave, CBET_MIN_WAVES) k_trace_window(const TraceArgs a)
+__global__ void __launch_bounds__(kWave) k_trace_window(const TraceArgs a)
 {
     using T = Tile<WZ>;            // box A
     using TB = Tile<8>;            // box B holds the few lanes that left A: single z-planes, half the LDS
@@ -308,7 +305,7 @@ __global__ void __launch_bounds__(kWave, CBET_MIN_WAVES) k_trace_window(const Tr
     if (!work_item(a, blockIdx.x, beam, patch)) return;
     // beam-resolved deposition (cbet_params.per_beam_grids): beam b accumulates into its own grid,
     // edep[b * grid_stride ...]; otherwise every beam adds into the one grid (grid_stride = 0)
-    double *const edep = a.edep + (long)beam * a.grid_stride;
+    double *const edep = a.edep + (long)(beam - a.grid_beam0) * a.grid_stride;
     const bool absorb = GENERIC ? (a.absorption == 1) : true;   // def.cuh:118
 
     Ray s;
@@ -362,7 +359,7 @@ __global__ void __launch_bounds__(kWave, CBET_MIN_WAVES) k_trace_window(const Tr
         kap = r.w;
     };
     if (alive) gather_record();
-    const double *const gk = CBET && a.gain ? a.gain + (long)beam * a.hsize : nullptr;  // this beam's gain grid
+    const double *const gk = CBET && a.gain ? a.gain + (long)(beam - a.grid_beam0) * a.hsize : nullptr;  // this beam's gain grid
     double gained = 0.0;                     // CBET: energy this lane's ray gained
     Deferred dfr;
     bool dfr_pending = false;                // wave-uniform: box A retired a plane in the previous step

@@ -87,24 +87,28 @@ class RayTracer:
         api.tabulate_plasma(self.ctx, self.params, self.d_te, self.d_r, self.d_ne, stream)
 
     def launch_cbet(self, out, gain_params, fields=False, gain=None, beam_gain=None, shard_index=0,
-                    shard_count=1, ne3d=None, kappa3d=None, beam_lo=0, beam_hi=None):
+                    shard_count=1, ne3d=None, kappa3d=None, beam_lo=0, beam_hi=None, grid_beam0=0, grid_beams=0):
         """One trace with the CBET hooks on torch's current stream (node tables must be filled:
         tabulate(), or pass ne3d / kappa3d).  fields=False: deposit the absorbed energy into `out`
-        ((n+2)^3 grid or nbeams of them); fields=True: the fused field pass, `out` = new_fields()."""
+        ((n+2)^3 grid or a grid per beam); fields=True: the fused field pass, `out` = new_fields().
+        grid_beams > 0: the beam-resolved arrays (`out` when it is per beam, `gain`) hold only the grids of
+        beams [grid_beam0, grid_beam0 + grid_beams) (cbet_params.grid_beam0 / grid_beams)."""
+        ngrids = grid_beams if grid_beams > 0 else self.params.nbeams
         if fields:
-            want = (4, self.params.nbeams) + self.grid_shape
+            want = (4, ngrids) + self.grid_shape
             per_beam = True
         else:
             per_beam = out.dim() == 4
-            want = ((self.params.nbeams,) + self.grid_shape) if per_beam else self.grid_shape
+            want = ((ngrids,) + self.grid_shape) if per_beam else self.grid_shape
         if out.dtype != torch.float64 or not out.is_contiguous() or tuple(out.shape) != want:
             raise ValueError("out must be a contiguous float64 tensor of shape %s" % (want,))
         if gain is not None and (gain.dtype != torch.float64 or not gain.is_contiguous() or
-                                 tuple(gain.shape) != (self.params.nbeams,) + self.grid_shape):
-            raise ValueError("gain must be a contiguous float64 tensor of shape nbeams x %s" % (self.grid_shape,))
+                                 tuple(gain.shape) != (ngrids,) + self.grid_shape):
+            raise ValueError("gain must be a contiguous float64 tensor of shape %s" % ((ngrids,) + self.grid_shape,))
         p = self.params.copy(per_beam_grids=1 if per_beam else 0, beam_lo=beam_lo,
                              beam_hi=self.params.nbeams if beam_hi is None else beam_hi,
-                             shard_index=shard_index, shard_count=shard_count)
+                             shard_index=shard_index, shard_count=shard_count,
+                             grid_beam0=grid_beam0, grid_beams=grid_beams)
         d = self.derived
         stream = torch.cuda.current_stream(self.device).cuda_stream
         api.trace_cbet(0, d.nindices, ne3d, kappa3d, gain, api.DEPOSIT_FIELDS if fields else api.DEPOSIT_ENERGY, out,
@@ -133,9 +137,10 @@ class RayTracer:
         engine = _DeviceCbetEngine(self, edep, gain_params, fields, gain)
         if slabs:
             rep = cbet_fixed_point_slabs(engine, gain_params, self.params.nbeams, self.grid_shape[0], rank, world_size, group)
+            rep["workspace_bytes"] = engine.slab_bytes()
         else:
             rep = cbet_fixed_point(engine, gain_params, rank, world_size, group)
-        rep["gain"] = engine.gain
+        rep["gain"] = engine.gain      # all beams (all-reduce loop) / this rank's beams (slab loop), whole grid
         return rep
 
     def node_tables(self):
@@ -166,23 +171,137 @@ def allreduce_grid(edep, group=None):
     initialised process group."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(edep, op=dist.ReduceOp.SUM, group=group)
+        if edep.is_cuda and dist.get_backend(group) != "nccl":   # gloo has no device path: stage through the host
+            host = edep.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            edep.copy_(host)
+        else:
+            dist.all_reduce(edep, op=dist.ReduceOp.SUM, group=group)
     return edep
 
 
+def reduce_scatter_grid(grid, slab, group=None, async_op=False):
+    """Combine the per-rank deposition grids so that rank r ends up with the SUM over ranks of x-slab r
+    (`slab` = planes [r P/W, (r+1) P/W) of the plane-padded grid, P a multiple of the world size W): a
+    reduce-scatter, half the xGMI traffic of the all-reduce and all a slab consumer (edepavg, a gain update, the
+    host copy of a slab) needs.  RCCL with backend "nccl"; gloo (CPU tests) has no reduce-scatter for this
+    layout, so there the grid is all-reduced and the slab copied out.  Returns the async work handle or None."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        slab.copy_(grid[: slab.shape[0]])
+        return None
+    if dist.get_backend(group) == "nccl":
+        return dist.reduce_scatter_tensor(slab, grid, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    host = grid.cpu() if grid.is_cuda else grid      # gloo has no device path: stage through the host
+    dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+    r, pl = dist.get_rank(group), slab.shape[0]
+    slab.copy_(host[r * pl:(r + 1) * pl])
+    return None
+
+
+class SweepPipeline:
+    """Independent passes of the plain path on one rank, pipelined over HIP streams (the passes of a sweep do not
+    feed each other: main.cu:96-232 run again on the same plasma).
+
+    Per pass k, with two alternating buffer sets b = k % 2 (deposition grid, node tables + step records = a
+    second context):
+        prep stream  : [tables b free = trace k-2 done, grid b free = combine k-2 done]  zero grid b,
+                       tabulate the node tables, build the step records
+        trace stream : [prep k done]  trace this rank's share of the bundles into grid b, then enqueue the combine
+        RCCL stream  : reduce-scatter of grid b over xGMI (torch's process-group stream, async)
+    so pass k+1's preparation runs beside the drain of trace k (a launch's last half millisecond runs at low
+    occupancy: it cannot be shorter than one bundle's lifetime) and combine k runs beside trace k+1.  Replaces
+    the serial launch -> D2H -> host sum of main.cu:166-210.  The combined result of a pass is slab r of the
+    grid on rank r (reduce_scatter_grid)."""
+
+    def __init__(self, tracer, rank=0, world_size=1, group=None):
+        self.tr, self.rank, self.world, self.group = tracer, rank, world_size, group
+        p = tracer.params
+        self.ctx = [tracer.ctx, api.Context(p, tracer.gpu)]
+        planes = -(-(p.nx + 2) // world_size) * world_size          # padded to a multiple of the world size
+        shape = (planes, p.ny + 2, p.nz + 2)
+        dev = tracer.device
+        self.grids = [torch.zeros(shape, dtype=torch.float64, device=dev) for _ in range(2)]
+        self.slabs = [torch.zeros((planes // world_size,) + shape[1:], dtype=torch.float64, device=dev) for _ in range(2)]
+        self.s_prep, self.s_trace = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        self.ev_prep = [torch.cuda.Event() for _ in range(2)]
+        self.ev_trace = [None, None]
+        self.work = [None, None]
+        self.kernel_events = []
+        si, sc = shard_of_rank(rank, world_size)
+        self.launch_p = p.copy(beam_lo=0, beam_hi=p.nbeams, shard_index=si, shard_count=sc)
+        self.passes = 0
+
+    def run_pass(self, timed=False):
+        tr, d, b = self.tr, self.tr.derived, self.passes % 2
+        self.passes += 1
+        with torch.cuda.stream(self.s_prep):
+            sp = self.s_prep.cuda_stream
+            if self.ev_trace[b] is not None:
+                self.s_prep.wait_event(self.ev_trace[b])
+            if self.work[b] is not None:
+                self.work[b].wait()            # this stream waits for combine k-2 before the grid is cleared
+                self.work[b] = None
+            self.grids[b].zero_()
+            api.tabulate_plasma(self.ctx[b], self.launch_p, tr.d_te, tr.d_r, tr.d_ne, sp)
+            api.prepare_step_records(self.ctx[b], self.launch_p, None, None, d.xconst, d.yconst, d.zconst, sp)
+            self.ev_prep[b].record()
+        with torch.cuda.stream(self.s_trace):
+            st = self.s_trace.cuda_stream
+            self.s_trace.wait_event(self.ev_prep[b])
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            api.trace_nodes(0, d.nindices, None, None, self.grids[b], tr.d_bbeam_norm, tr.d_beam_norm, tr.d_pow_r,
+                            tr.d_phase_r, d.xconst, d.yconst, d.zconst, self.launch_p, self.ctx[b], st)
+            if timed:
+                e1.record()
+                self.kernel_events.append((e0, e1))
+            self.ev_trace[b] = torch.cuda.Event()
+            self.ev_trace[b].record()
+            self.work[b] = reduce_scatter_grid(self.grids[b], self.slabs[b], self.group, async_op=True)
+        return b
+
+    def finish(self):
+        """Wait for everything in flight; returns the slab of the last pass (this rank's planes of the sum)."""
+        for b in range(2):
+            if self.work[b] is not None:
+                self.work[b].wait()
+                self.work[b] = None
+        torch.cuda.synchronize(self.tr.device)
+        return self.slabs[(self.passes - 1) % 2] if self.passes else None
+
+    def counters(self, reset=False):
+        stream = torch.cuda.current_stream(self.tr.device).cuda_stream
+        c0, c1 = self.ctx[0].counters(stream, reset), self.ctx[1].counters(stream, reset)
+        for name, _ in api.Counters._fields_:
+            setattr(c0, name, getattr(c0, name) + getattr(c1, name))
+        return c0
+
+    def close(self):
+        self.finish()
+        self.ctx[1].close()
+
+
 class _DeviceCbetEngine:
-    """The per-rank compute of the CBET iteration on a RayTracer's device (see cbet_fixed_point)."""
+    """The per-rank compute of the CBET iteration on a RayTracer's device (see cbet_fixed_point and
+    cbet_fixed_point_slabs).  The all-reduce loop keeps every beam's arrays over the whole grid
+    (cbet_cbet_workspace_bytes: 49.5 GB at 256^3 / 60 beams); the slab-owned loop allocates, in begin_slabs, only
+    its own beams over the whole grid and all beams over its own x-slab (cbet_cbet_slab_workspace_bytes)."""
 
     def __init__(self, tracer, edep, gain_params, fields=None, gain=None):
         self.tr, self.edep, self.gp = tracer, edep, gain_params
-        self.fields = tracer.new_fields() if fields is None else fields
-        self.gain = tracer.new_grid(per_beam=True) if gain is None else gain
-        self.scratch = torch.empty_like(self.gain)
+        self._fields, self._gain = fields, gain
         self.change = torch.zeros(2, dtype=torch.float64, device=tracer.device)
         self.beam_gain = torch.zeros(tracer.params.nbeams, dtype=torch.float64, device=tracer.device)
 
+    # ---- all-reduce loop: whole-grid arrays of every beam
     def begin(self):
-        self.tr.tabulate()
+        tr = self.tr
+        self.fields = tr.new_fields() if self._fields is None else self._fields
+        self.gain = tr.new_grid(per_beam=True) if self._gain is None else self._gain
+        self.scratch = torch.empty_like(self.gain)
+        tr.tabulate()
         self.gain.zero_()
 
     def field_passes(self, use_gain, shard_index, shard_count):
@@ -196,28 +315,62 @@ class _DeviceCbetEngine:
         self.tr.gain_field(fields, self.gain, self.gp, self.change, scratch=self.scratch)
         return self.change
 
-    # the slab-owned variant (cbet_fixed_point_slabs): whole beams per rank, the gain update per x-slab
-    def field_passes_beams(self, use_gain, beam_lo, beam_hi):
-        self.fields.zero_()
-        self.tr.launch_cbet(self.fields, self.gp, fields=True, gain=self.gain if use_gain else None,
-                            beam_lo=beam_lo, beam_hi=beam_hi)
-        return self.fields
-
-    def update_gain_slab(self, fields, x_lo, x_hi):
-        self.change.zero_()
-        self.tr.gain_field(fields, self.gain, self.gp, self.change, scratch=self.scratch, x_lo=x_lo, x_hi=x_hi)
-        return self.change
-
-    def deposit_beams(self, beam_lo, beam_hi):
-        self.beam_gain.zero_()
-        self.tr.launch_cbet(self.edep, self.gp, gain=self.gain, beam_gain=self.beam_gain, beam_lo=beam_lo, beam_hi=beam_hi)
-        return self.beam_gain
-
     def deposit(self, shard_index, shard_count):
         self.beam_gain.zero_()
         self.tr.launch_cbet(self.edep, self.gp, gain=self.gain, beam_gain=self.beam_gain,
                             shard_index=shard_index, shard_count=shard_count)
         return self.beam_gain
+
+    # ---- slab-owned loop: own beams [b0, b1) over the whole grid, all beams over the own planes [x0, x1)
+    def begin_slabs(self, b0, b1, x0, x1):
+        tr, dev = self.tr, self.tr.device
+        nb, gs = tr.params.nbeams, tr.grid_shape
+        self.b0, self.b1, self.x0, self.x1 = b0, b1, x0, x1
+        f64 = dict(dtype=torch.float64, device=dev)
+        self.own_fields = torch.zeros((4, b1 - b0) + gs, **f64)
+        self.gain_own = torch.zeros((b1 - b0,) + gs, **f64)
+        self.slab_fields = torch.zeros((4, nb, x1 - x0) + gs[1:], **f64)
+        self.gain_slab = torch.zeros((nb, x1 - x0) + gs[1:], **f64)
+        self.scratch_slab = torch.empty((nb, x1 - x0) + gs[1:], **f64)
+        self.gain = self.gain_own            # what a caller gets back: this rank's beams over the whole grid
+        tr.tabulate()
+
+    def slab_bytes(self):
+        return 8 * sum(t.numel() for t in (self.own_fields, self.gain_own, self.slab_fields, self.gain_slab, self.scratch_slab))
+
+    def field_passes_beams(self, use_gain):
+        self.own_fields.zero_()
+        if self.b1 > self.b0:
+            self.tr.launch_cbet(self.own_fields, self.gp, fields=True, gain=self.gain_own if use_gain else None,
+                                beam_lo=self.b0, beam_hi=self.b1, grid_beam0=self.b0, grid_beams=self.b1 - self.b0)
+        return self.own_fields
+
+    def update_gain_slab(self):
+        self.change.zero_()
+        if self.x1 > self.x0:
+            stream = torch.cuda.current_stream(self.tr.device).cuda_stream
+            api.gain_field_packed(self.slab_fields, None, self.gain_slab, self.scratch_slab, self.change, self.x0, self.x1,
+                                  self.tr.params, self.gp, self.tr.ctx, stream)
+        return self.change
+
+    def deposit_beams(self):
+        self.beam_gain.zero_()
+        if self.b1 > self.b0:
+            self.tr.launch_cbet(self.edep, self.gp, gain=self.gain_own, beam_gain=self.beam_gain, beam_lo=self.b0,
+                                beam_hi=self.b1, grid_beam0=self.b0, grid_beams=self.b1 - self.b0)
+        return self.beam_gain
+
+
+def _agree(t, group, world_size):
+    """Make a small per-rank tensor that steers control flow identical on all ranks (rank 0's copy): collectives
+    need not return bit-identical values everywhere, and a stop decision taken from slightly different numbers
+    would leave ranks waiting in different collectives."""
+    import torch.distributed as dist
+    if world_size > 1:
+        host = t.detach().cpu()
+        dist.broadcast(host, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
+        return host
+    return t.detach().cpu()
 
 
 def cbet_fixed_point(engine, gain_params, rank=0, world_size=1, group=None):
@@ -226,8 +379,8 @@ def cbet_fixed_point(engine, gain_params, rank=0, world_size=1, group=None):
     Every pass: each rank deposits the four field components of ITS share of the ray bundles (the plain
     pass's interleaved sharding), the fields are summed over ranks with one all-reduce, and every rank
     updates the full gain coefficient from them (redundantly -- it needs all of it for its own rays).
-    Stops when sum |dK| / sum |K| < tolerance, then runs the deposition pass and all-reduces the
-    per-beam energy balance.  `engine` supplies the per-rank compute:
+    Stops when sum |dK| / sum |K| < tolerance (rank 0's value, broadcast), then runs the deposition pass and
+    all-reduces the per-beam energy balance.  `engine` supplies the per-rank compute:
         begin(); field_passes(use_gain, shard_index, shard_count) -> fields tensor;
         update_gain(fields) -> tensor {sum |dK|, sum |K|}; deposit(shard_index, shard_count) -> beam_gain tensor
     (the device engine is RayTracer.cbet_solve's; the CPU tests drive this loop with an oracle engine).
@@ -239,7 +392,7 @@ def cbet_fixed_point(engine, gain_params, rank=0, world_size=1, group=None):
         fields = engine.field_passes(it > 0, si, sc)
         if world_size > 1:
             allreduce_grid(fields, group)
-        ch = engine.update_gain(fields).cpu()
+        ch = _agree(engine.update_gain(fields), group, world_size)
         rep["passes"] = it + 1
         rep["change"] = float(ch[0] / ch[1]) if float(ch[1]) > 0 else 0.0
         if rep["change"] < gain_params.tolerance:
@@ -255,72 +408,92 @@ def cbet_fixed_point(engine, gain_params, rank=0, world_size=1, group=None):
 
 
 def _parts(total, world_size):
-    """Contiguous near-equal parts of range(total): [(lo, hi)] per rank."""
+    """Contiguous near-equal parts of range(total): [(lo, hi)] per rank (cbet_cbet_slab_workspace_bytes uses the
+    same rule).  Parts are empty when world_size > total."""
     return [((r * total) // world_size, ((r + 1) * total) // world_size) for r in range(world_size)]
 
 
-def _exchange(tensor, send_index, recv_index, rank, world_size, group):
-    """Point-to-point exchange over xGMI / RCCL (gloo in the CPU tests): rank r sends tensor[send_index(s)] to
-    every other rank s and stores what s sends it in tensor[recv_index(s)].  Index tuples select strided views;
-    the copies to and from contiguous staging buffers are the pack / unpack of an all-to-all."""
+def _exchange(src, send_index, dst, recv_index, rank, world_size, group):
+    """All-to-all over point-to-point xGMI links (RCCL send/recv; gloo in the CPU tests): rank r sends
+    src[send_index(s)] to every other rank s and stores what s sends it in dst[recv_index(s)]; its own part is
+    copied.  Index tuples select strided views; the copies to and from contiguous staging buffers are the pack /
+    unpack of the exchange.  Empty parts (a rank without beams or planes) are skipped on both sides.  With a
+    backend that has no device path (gloo) device tensors are staged through the host."""
     import torch.distributed as dist
+    dst[recv_index(rank)] = src[send_index(rank)]
+    if world_size == 1:
+        return
+    via_host = src.is_cuda and dist.get_backend(group) != "nccl"
     ops, inbox = [], []
     for s in range(world_size):
         if s == rank:
             continue
-        out = tensor[send_index(s)].contiguous()
-        buf = torch.empty_like(tensor[recv_index(s)], memory_format=torch.contiguous_format)
-        inbox.append((s, buf))
-        ops.append(dist.P2POp(dist.isend, out, s if group is None else dist.get_global_rank(group, s), group))
-        ops.append(dist.P2POp(dist.irecv, buf, s if group is None else dist.get_global_rank(group, s), group))
+        peer = s if group is None else dist.get_global_rank(group, s)
+        out = src[send_index(s)]
+        if out.numel():
+            out = out.contiguous()
+            ops.append(dist.P2POp(dist.isend, out.cpu() if via_host else out, peer, group))
+        want = dst[recv_index(s)]
+        if want.numel():
+            buf = torch.empty(want.shape, dtype=want.dtype, device="cpu" if via_host else want.device)
+            inbox.append((s, buf))
+            ops.append(dist.P2POp(dist.irecv, buf, peer, group))
     if ops:
-        if tensor.is_cuda:   # staging copies done before a backend that is not stream-ordered (gloo) reads them
-            torch.cuda.current_stream(tensor.device).synchronize()
+        if src.is_cuda and not via_host:   # the staging copies are on the current stream; the collective runs on RCCL's
+            torch.cuda.current_stream(src.device).synchronize()
         for req in dist.batch_isend_irecv(ops):
             req.wait()
-        if tensor.is_cuda:
-            torch.cuda.synchronize(tensor.device)
+        if src.is_cuda and not via_host:
+            torch.cuda.synchronize(src.device)
     for s, buf in inbox:
-        tensor[recv_index(s)] = buf
+        dst[recv_index(s)] = buf.to(dst.device)
 
 
 def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_size=1, group=None):
-    """The CBET fixed-point iteration with the exchange sized for point-to-point xGMI (parity
-    unpinned; same passes and same result as cbet_fixed_point).
+    """The CBET fixed-point iteration with storage and exchange sized for 8 ranks on point-to-point xGMI (SURVEY
+    8(f) f1; parity unpinned; same passes and same result as cbet_fixed_point).
 
     Rank r traces WHOLE beams [b_r0, b_r1) -- their four fields are complete on r without any reduction -- and
-    owns the x-slab [x_r0, x_r1) of the deposit grid for the gain update.  Per pass: (1) every rank sends, to each
-    slab owner, its beams' fields over that slab (all-to-all, (world-1)/world of the rank's own 4 nb_r grids
-    instead of an all-reduce of all 4 nb grids); (2) each rank updates the gain coefficient of ALL beams on its
-    slab; (3) it sends every other rank the gain of that rank's beams over its slab (all-to-all, nb_r grids);
-    (4) two scalars are all-reduced for the convergence measure.  At 256^3 / 60 beams / 8 ranks that is 3.6 GB +
-    0.9 GB sent per rank and pass, against 58 GB of ring traffic per rank for the all-reduce of cbet_fixed_point.
-    `engine`: begin(); field_passes_beams(use_gain, b0, b1) -> fields [4][nb][x][y][z]; update_gain_slab(fields, x0,
-    x1) -> tensor {sum |dK|, sum |K|} over the slab; deposit_beams(b0, b1) -> beam_gain; attribute `gain`
-    [nb][x][y][z].  The deposition grid is left un-reduced (allreduce_grid), as in cbet_fixed_point."""
+    owns the x-slab [x_r0, x_r1) of the deposit grid for the gain update.  It STORES only
+        its own beams over the whole grid : own_fields [4][nb_r][X][Y][Z], gain_own [nb_r][X][Y][Z]
+        all beams over its own slab       : slab_fields [4][nb][x_r][Y][Z], gain_slab and scratch [nb][x_r][Y][Z]
+    i.e. (5 nb_r + 6 nb / W) grids instead of 6 nb: 92 GB per rank at 512^3 / 60 beams / 8 ranks against 391 GB
+    (cbet_cbet_slab_workspace_bytes).  Per pass: (1) every rank sends each slab owner its beams' fields over that
+    slab (all-to-all, (W-1)/W of own_fields); (2) each rank updates the gain of ALL beams on its slab; (3) it sends
+    every rank the gain of that rank's beams over its slab (all-to-all, gain_slab); (4) two scalars are
+    all-reduced for the convergence measure and rank 0's copy decides.  At 256^3 / 60 beams / 8 ranks that is
+    3.6 GB + 0.9 GB sent per rank and pass, against 58 GB of ring traffic per rank for the all-reduce loop.
+    `engine`: begin_slabs(b0, b1, x0, x1); field_passes_beams(use_gain) -> own_fields; attributes slab_fields,
+    gain_slab, gain_own; update_gain_slab() -> tensor {sum |dK|, sum |K|} over the slab; deposit_beams() ->
+    beam_gain.  The deposition grid is left un-reduced (allreduce_grid / reduce_scatter_grid)."""
     import torch.distributed as dist
     beams, slabs = _parts(nbeams, world_size), _parts(nx_halo, world_size)
     (b0, b1), (x0, x1) = beams[rank], slabs[rank]
-    engine.begin()
+    engine.begin_slabs(b0, b1, x0, x1)
     rep = {"passes": 0, "converged": False, "change": float("inf")}
     for it in range(gain_params.max_passes):
-        fields = engine.field_passes_beams(it > 0, b0, b1)
-        if world_size > 1:   # my beams' fields over slab s -> rank s; rank q's beams over my slab <- rank q
-            _exchange(fields, lambda s: (slice(None), slice(b0, b1), slice(*slabs[s])),
-                      lambda q: (slice(None), slice(*beams[q]), slice(x0, x1)), rank, world_size, group)
-        ch = engine.update_gain_slab(fields, x0, x1)
+        own = engine.field_passes_beams(it > 0)
+        # my beams' fields over slab s -> rank s; rank q's beams over my slab <- rank q
+        _exchange(own, lambda s: (slice(None), slice(None), slice(*slabs[s])),
+                  engine.slab_fields, lambda q: (slice(None), slice(*beams[q])), rank, world_size, group)
+        ch = engine.update_gain_slab()
         if world_size > 1:
-            dist.all_reduce(ch, op=dist.ReduceOp.SUM, group=group)
-            # the gain of rank r's beams over my slab -> rank r; my beams' gain over slab s <- rank s
-            _exchange(engine.gain, lambda r: (slice(*beams[r]), slice(x0, x1)),
-                      lambda s: (slice(b0, b1), slice(*slabs[s])), rank, world_size, group)
-        ch = ch.cpu()
+            if ch.is_cuda and dist.get_backend(group) != "nccl":
+                host = ch.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+                ch = host
+            else:
+                dist.all_reduce(ch, op=dist.ReduceOp.SUM, group=group)
+        # the gain of rank q's beams over my slab -> rank q; my beams' gain over slab s <- rank s
+        _exchange(engine.gain_slab, lambda q: (slice(*beams[q]),),
+                  engine.gain_own, lambda s: (slice(None), slice(*slabs[s])), rank, world_size, group)
+        ch = _agree(ch, group, world_size)
         rep["passes"] = it + 1
         rep["change"] = float(ch[0] / ch[1]) if float(ch[1]) > 0 else 0.0
         if rep["change"] < gain_params.tolerance:
             rep["converged"] = True
             break
-    beam_gain = engine.deposit_beams(b0, b1)
+    beam_gain = engine.deposit_beams()
     if world_size > 1:
         allreduce_grid(beam_gain, group)
     bg = beam_gain.cpu().numpy().copy()

@@ -72,6 +72,16 @@ typedef struct cbet_params {
     int patch_order;             /* 1 = longest first: a beam's patches are listed by descending      */
                                  /* launch radius (outer rays take ~3x the steps of central ones);     */
                                  /* 0 = Morton curve.  Part of the geometry a context is created for.  */
+    int grid_beam0, grid_beams;  /* beam-resolved arrays (per_beam_grids output, the field pass's output, the  */
+                                 /* gain coefficient) that hold only the grids of beams [grid_beam0,          */
+                                 /* grid_beam0 + grid_beams): beam b uses grid b - grid_beam0.  grid_beams = 0 */
+                                 /* (default): the arrays hold all nbeams grids.  This is how a rank of the    */
+                                 /* slab-owned CBET loop keeps only ITS beams' fields and gain.                */
+    int order_phases;            /* work-item order: 1 = beam-major (beam by beam, each beam's patches in   */
+                                 /* list order); 2 = every beam's long bundles (the first third of its      */
+                                 /* list) first, then every beam's short ones, so that a short launch ends  */
+                                 /* on short bundles; -1 = auto: 2 for sharded launches (shard_count > 1),  */
+                                 /* 1 otherwise                                                              */
 } cbet_params;
 
 /* Quantities the reference derives in def.cuh / main.cu:156-161, evaluated in the same order. */
@@ -120,8 +130,8 @@ int cbet_derive(const cbet_params *p, cbet_derived *d);
  * section is cut into 8x8-ray patches (cbet_params.patch_order); 64 consecutive entries = one patch = one ray
  * bundle = one wavefront.  An entry is the thread-ray id (launch_ray_XZ.cu:125,156) of that ray,
  * or -1 for a hole: a ray the reference launch shape never visits or one that fails init()'s
- * beam-radius test (:94,114).  Work items g are (beam, patch) pairs, beam by beam, patch by patch;
- * item g is traced by shard g % shard_count.
+ * beam-radius test (:94,114).  Work items g are (beam, patch) pairs in the order of
+ * cbet_params.order_phases; item g is traced by shard g % shard_count.
  * Writes min(n, cap) entries to out (may be NULL) and n to *count.
  */
 int cbet_live_ray_list(const cbet_params *p, int *out, long cap, long *count);
@@ -203,6 +213,11 @@ int cbet_launch_ray_XYZ(int b, unsigned nindices, double *te_data_g, double *r_d
  *       interpolate at each node, launch_ray_XZ.cu:254-265, 296-305).
  *   cbet_trace_nodes     : trace using caller-supplied node tables ne3d / kappa3d of nx*ny*nz
  *       doubles (NULL = the context's own), i.e. an arbitrary, not necessarily spherical, plasma.
+ *   cbet_prepare_step_records : optional.  The default kernel gathers ONE 32-byte record per node and step
+ *       -- the three velocity kicks xconst * (ne(x+1) - ne(x-1)) of launch_ray_XZ.cu:268-270 with the face
+ *       rule of :212-238, and kappa3d -- which a launch builds from the tables and xconst / yconst / zconst
+ *       when they are not current.  Calling this first moves that pass (0.15 ms at 256^3) out of the launch;
+ *       records built from the context's own tables stay valid until the next cbet_tabulate_plasma.
  */
 int cbet_tabulate_plasma(cbet_context *ctx, const cbet_params *p, const double *te_data_g,
                          const double *r_data_g, const double *ne_data_g, void *stream);
@@ -210,6 +225,9 @@ int cbet_trace_nodes(int b, unsigned nindices, const double *ne3d, const double 
                      double *edep, const double *bbeam_norm, const double *beam_norm,
                      const double *pow_r, const double *phase_r, double xconst, double yconst,
                      double zconst, const cbet_params *p, cbet_context *ctx, void *stream);
+int cbet_prepare_step_records(cbet_context *ctx, const cbet_params *p, const double *ne3d,
+                              const double *kappa3d, double xconst, double yconst, double zconst,
+                              void *stream);
 
 /* ---- orchestrator ---------------------------------------------------------------------------- */
 /*
@@ -331,6 +349,21 @@ int cbet_gain_field(double *fields, const double *ne3d, double *gain, double *sc
 int cbet_gain_field_slab(double *fields, const double *ne3d, double *gain, double *scratch, double *change,
                          int hx_lo, int hx_hi, const cbet_params *p, const cbet_gain_params *g,
                          cbet_context *ctx, void *stream);
+/*
+ * cbet_gain_field_slab on SLAB-PACKED arrays: fields [4][nbeams][slab], gain and scratch [nbeams][slab] hold only
+ * the planes [hx_lo, hx_hi) of every beam's haloed grid (slab = (hx_hi - hx_lo)(ny+2)(nz+2) doubles per beam and
+ * component) -- what one rank of the slab-owned loop stores: all beams over its own x-slab.
+ */
+int cbet_gain_field_packed(double *fields, const double *ne3d, double *gain, double *scratch, double *change,
+                         int hx_lo, int hx_hi, const cbet_params *p, const cbet_gain_params *g,
+                         cbet_context *ctx, void *stream);
+/*
+ * Device bytes one rank of the slab-owned CBET loop (tracer.cbet_fixed_point_slabs) needs beside the node tables:
+ * its own beams' four field components and gain over the whole grid, all beams' fields, gain and scratch over
+ * its x-slab.  0 on bad arguments.  (512^3, 60 beams, 8 ranks: ~92 GB per rank; every rank holding everything,
+ * cbet_cbet_workspace_bytes, would be 391 GB.)
+ */
+size_t cbet_cbet_slab_workspace_bytes(const cbet_params *p, int world_size, int rank);
 /* Bytes of device workspace cbet_cbet_solve needs: 6 nbeams (n+2)^3 doubles + a few scalars. */
 size_t cbet_cbet_workspace_bytes(const cbet_params *p);
 /*

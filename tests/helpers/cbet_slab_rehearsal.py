@@ -1,11 +1,11 @@
 """Rehearsal of the multi-rank CBET loops with the real device engine: W ranks share GPU 0 (gloo carries the
 exchanges), every rank runs RayTracer.cbet_solve in both the all-reduce and the slab-owned form, and rank 0
 compares the combined deposition grids with a single-rank solve.
-usage: python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 scripts/cbet_slab_rehearsal.py [n=32]"""
+usage: python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 tests/helpers/cbet_slab_rehearsal.py [n=32]"""
 import os, sys
 import numpy as np, torch
 import torch.distributed as dist
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import load_inputs, parity_err
 from cbet_raytracing_3d_amd import api

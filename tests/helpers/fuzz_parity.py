@@ -1,9 +1,9 @@
 """Randomised parity sweep on the GPU: small random grids (ragged, tiny, face-hugging), beam subsets, rays per
 zone, absorption on/off, sharding, beam-resolved grids, all three kernel formulations -- every case against
-the CPU oracle (SURVEY 8(c) metric <= 1e-9, equal ray-step counts).  usage: python scripts/fuzz_parity.py [cases=40] [seed=1]"""
+the CPU oracle (SURVEY 8(c) metric <= 1e-9, equal ray-step counts).  usage: python tests/helpers/fuzz_parity.py [cases=40] [seed=1]"""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import load_inputs, parity_err
 from cbet_raytracing_3d_amd import api

@@ -134,6 +134,25 @@ def test_gain_params_and_constants_host_side(api, oracle, case):
     assert ei.value.code == api.EINVAL
 
 
+def test_slab_workspace_fits_config5(api):
+    """BASELINE config 5 (512^3, 60 beams, 8 ranks): the slab-owned loop's per-rank storage must fit 288 GB of HBM
+    with the node tables and step records beside it; every rank holding everything would not (391 GB)."""
+    p = api.default_params(512)
+    hsize, plane = 514 ** 3, 514 ** 2
+    tables = 8 * 512 ** 3 * (2 + 4) * 2             # ne3d + kappa3d + 32-byte step records, two buffer sets
+    worst = 0
+    for rank in range(8):
+        b = api.cbet_slab_workspace_bytes(p, 8, rank)
+        nb_r = (rank + 1) * 60 // 8 - rank * 60 // 8
+        planes = (rank + 1) * 514 // 8 - rank * 514 // 8
+        assert b == 8 * (5 * nb_r * hsize + 6 * 60 * planes * plane + 2 + api.MAX_CBET_BEAMS)
+        worst = max(worst, b)
+    assert worst + tables < 288e9 and worst < 100e9
+    assert api.cbet_workspace_bytes(p) > 288e9       # the all-reduce loop's whole-grid arrays do not fit
+    assert api.cbet_slab_workspace_bytes(p, 8, 8) == 0 and api.cbet_slab_workspace_bytes(p, 0, 0) == 0
+    assert api.cbet_slab_workspace_bytes(api.default_params(256), 1, 0) == api.cbet_workspace_bytes(api.default_params(256)) + 8 * 5 * 60 * 258 ** 3
+
+
 class _OracleEngine:
     """cbet_fixed_point's per-rank compute with the oracle standing in for the device."""
 
@@ -166,30 +185,48 @@ class _OracleEngine:
         self.steps = steps
         return torch.from_numpy(bg)
 
-    # the slab-owned loop (cbet_fixed_point_slabs): whole beams per rank, the gain update per x-slab.  `gain` is a
-    # torch view of the numpy array so that the exchange can fill it in place.
-    def _beam_items(self, b0, b1):
+    # the slab-owned loop (cbet_fixed_point_slabs): whole beams per rank, the gain update per x-slab, and only
+    # (own beams x whole grid) + (all beams x own slab) stored -- torch tensors, filled in place by the exchange
+    def begin_slabs(self, b0, b1, x0, x1):
+        gs = self.O.grid_shape(self.cfg)
+        self.b0, self.b1, self.x0, self.x1 = b0, b1, x0, x1
+        self.gain_own = torch.zeros((b1 - b0,) + gs, dtype=torch.float64)
+        self.slab_fields = torch.zeros((4, self.nb, x1 - x0) + gs[1:], dtype=torch.float64)
+        self.gain_slab = torch.zeros((self.nb, x1 - x0) + gs[1:], dtype=torch.float64)
+        self.stored = 4 * (b1 - b0) * int(np.prod(gs)) + self.gain_own.numel() + self.slab_fields.numel() + 2 * self.gain_slab.numel()
+
+    def _beam_items(self):
         beams, ids = self.api.shard_items(self.p, self.nb, 0, 1)
-        keep = (np.asarray(beams) >= b0) & (np.asarray(beams) < b1)
+        keep = (np.asarray(beams) >= self.b0) & (np.asarray(beams) < self.b1)
         return np.asarray(beams)[keep], np.asarray(ids)[keep]
 
-    def field_passes_beams(self, use_gain, b0, b1):
-        gain = self.gain.numpy() if use_gain else None
-        F = [self.O.trace_cbet(self.cfg, self.g, self.bn, self.ne3d, self.kap, gain=gain, quantity=q, per_beam=True,
-                               nthreads=2, items=self._beam_items(b0, b1))[0] for q in (1, 2, 3, 4)]
+    def _full_gain(self):      # the oracle takes a gain array over all beams; only this rank's beams are traced
+        g = np.zeros((self.nb,) + self.O.grid_shape(self.cfg))
+        g[self.b0:self.b1] = self.gain_own.numpy()
+        return g
+
+    def field_passes_beams(self, use_gain):
+        F = [self.O.trace_cbet(self.cfg, self.g, self.bn, self.ne3d, self.kap, gain=self._full_gain() if use_gain else None,
+                               quantity=q, per_beam=True, nthreads=2, items=self._beam_items())[0][self.b0:self.b1]
+             for q in (1, 2, 3, 4)]
         return torch.from_numpy(np.stack(F))
 
-    def update_gain_slab(self, fields, x0, x1):
-        # the oracle updates every cell; only this rank's slab is kept (elsewhere its fields are incomplete)
-        old = self.gain.numpy()
-        new, _ = self.O.gain_field(self.cfg, self.g, fields.numpy(), self.ne3d, relax=1.0, gain=old.copy(), nthreads=2)
-        ch = [np.abs(new[:, x0:x1] - old[:, x0:x1]).sum(), np.abs(new[:, x0:x1]).sum()]
-        old[:, x0:x1] = new[:, x0:x1]
+    def update_gain_slab(self):
+        # the oracle updates whole grids: embed the slab (zero fields elsewhere), keep the slab of the result
+        gs = self.O.grid_shape(self.cfg)
+        F = np.zeros((4, self.nb) + gs)
+        F[:, :, self.x0:self.x1] = self.slab_fields.numpy()
+        old = np.zeros((self.nb,) + gs)
+        old[:, self.x0:self.x1] = self.gain_slab.numpy()
+        new, _ = self.O.gain_field(self.cfg, self.g, F, self.ne3d, relax=1.0, gain=old.copy(), nthreads=2)
+        sl = new[:, self.x0:self.x1]
+        ch = [np.abs(sl - self.gain_slab.numpy()).sum(), np.abs(sl).sum()]
+        self.gain_slab.copy_(torch.from_numpy(np.ascontiguousarray(sl)))
         return torch.tensor(ch, dtype=torch.float64)
 
-    def deposit_beams(self, b0, b1):
-        e, steps, bg = self.O.trace_cbet(self.cfg, self.g, self.bn, self.ne3d, self.kap, gain=self.gain.numpy(), nthreads=2,
-                                         items=self._beam_items(b0, b1))
+    def deposit_beams(self):
+        e, steps, bg = self.O.trace_cbet(self.cfg, self.g, self.bn, self.ne3d, self.kap, gain=self._full_gain(), nthreads=2,
+                                         items=self._beam_items())
         self.edep += e
         self.steps = steps
         return torch.from_numpy(bg)
@@ -206,12 +243,12 @@ def _solve(rank, world, group=None, slabs=False):
     eng = _OracleEngine(O, api, cfg, O.gain_default(), bn[BEAMS].copy(), ne3d, kap, len(BEAMS))
     gp = api.default_gain_params(relax=1.0, tolerance=1e-5, max_passes=8)
     if slabs:
-        class _Slabbed(_OracleEngine):      # same engine, `gain` held as a torch view for the in-place exchange
-            def begin(self):
-                self.gain = torch.zeros((self.nb,) + self.O.grid_shape(self.cfg), dtype=torch.float64)
-        eng.__class__ = _Slabbed
         rep = cbet_fixed_point_slabs(eng, gp, len(BEAMS), N + 2, rank, world, group)
-        eng.gain = eng.gain.numpy()
+        eng.gain = eng.gain_own.numpy()          # this rank's beams over the whole grid
+        # what the rank stored: (5 nb_r + 6 nb / W) grids, never 6 nb
+        full = (N + 2) ** 3
+        assert eng.stored == (5 * (eng.b1 - eng.b0) * (N + 2) + 6 * len(BEAMS) * (eng.x1 - eng.x0)) * (N + 2) ** 2
+        assert world == 1 or eng.stored < 6 * len(BEAMS) * full
     else:
         rep = cbet_fixed_point(eng, gp, rank, world, group)
     edep = torch.from_numpy(eng.edep)
@@ -290,5 +327,6 @@ def test_slab_owned_iteration_equals_unsharded(tmp_path, api, oracle, world):
     assert int(got["steps"]) == steps
     assert parity_err(got["edep"], edep) < 1e-9
     b0, b1 = 0, (len(BEAMS)) // world        # rank 0 holds the gain of its own beams over the whole grid
-    assert np.abs(got["gain"][b0:b1] - gain[b0:b1]).max() < 1e-9 * np.abs(gain).max()
+    assert got["gain"].shape[0] == b1 - b0
+    assert np.abs(got["gain"] - gain[b0:b1]).max() < 1e-9 * np.abs(gain).max()
     assert np.abs(got["beam_gain"] - rep["beam_gain"]).max() < 1e-9 * np.abs(rep["beam_gain"]).max()

@@ -256,6 +256,43 @@ def test_gain_update_by_slabs_equals_the_whole(api, setup, torch_cuda):
         tr.gain_field(fields, parts, gp, None, x_lo=5, x_hi=N + 3)
 
 
+def test_packed_slab_storage_equals_whole_grid_storage(api, setup, torch_cuda):
+    """cbet_gain_field_packed / cbet_params.grid_beam0, grid_beams: arrays that hold only one x-slab of every beam,
+    or only some beams' grids, must give bit for bit what the whole arrays give (the storage one rank of the
+    slab-owned loop keeps)."""
+    tr, gp = setup["tr"], setup["gp"]
+    stream = torch_cuda.cuda.current_stream().cuda_stream
+    fields = torch_cuda.from_numpy(setup["ofields"].copy()).cuda()
+    x0, x1 = 9, 22
+    for sym in (False, True):
+        ref = tr.new_grid(per_beam=True)
+        f_ref = fields.clone()
+        ch_ref = torch_cuda.zeros(2, dtype=torch_cuda.float64, device="cuda")
+        tr.gain_field(f_ref, ref, gp, ch_ref, scratch=torch_cuda.empty_like(ref) if sym else None, x_lo=x0, x_hi=x1)
+        f_pk = fields[:, :, x0:x1].contiguous()
+        g_pk = torch_cuda.zeros_like(ref[:, x0:x1]).contiguous()
+        ch = torch_cuda.zeros(2, dtype=torch_cuda.float64, device="cuda")
+        api.gain_field_packed(f_pk, None, g_pk, torch_cuda.empty_like(g_pk) if sym else None, ch, x0, x1, tr.params, gp,
+                              tr.ctx, stream)
+        assert torch_cuda.equal(g_pk, ref[:, x0:x1]) and torch_cuda.equal(f_pk, f_ref[:, :, x0:x1])
+        assert float(((ch - ch_ref).abs() / ch_ref).max()) < 1e-12      # atomically accumulated: order differs
+    # beams [2, 5) only: field pass and deposition pass with compact arrays against slices of the full ones
+    gain = torch_cuda.from_numpy(setup["ogain"].copy()).cuda()
+    full_f, full_e = tr.new_fields(), tr.new_grid()
+    tr.launch_cbet(full_f, gp, fields=True, gain=gain, beam_lo=2, beam_hi=5)
+    tr.launch_cbet(full_e, gp, gain=gain, beam_lo=2, beam_hi=5)
+    part_f = torch_cuda.zeros((4, 3) + tr.grid_shape, dtype=torch_cuda.float64, device="cuda")
+    part_e = tr.new_grid()
+    gpart = gain[2:5].contiguous()
+    tr.launch_cbet(part_f, gp, fields=True, gain=gpart, beam_lo=2, beam_hi=5, grid_beam0=2, grid_beams=3)
+    tr.launch_cbet(part_e, gp, gain=gpart, beam_lo=2, beam_hi=5, grid_beam0=2, grid_beams=3)
+    assert parity_err(part_f.cpu().numpy().reshape(-1), full_f[:, 2:5].cpu().numpy().reshape(-1)) < TOL
+    assert float(full_f[:, :2].abs().sum()) == 0.0 and float(full_f[:, 5:].abs().sum()) == 0.0
+    assert parity_err(part_e.cpu().numpy(), full_e.cpu().numpy()) < TOL
+    with pytest.raises(api.CbetError):        # beams outside the compact arrays' range
+        tr.launch_cbet(part_f, gp, fields=True, beam_lo=1, beam_hi=4, grid_beam0=2, grid_beams=3)
+
+
 def test_slab_owned_loop_on_one_rank_equals_the_plain_loop(api, setup, torch_cuda):
     """RayTracer.cbet_solve(slabs=True) with world_size 1 (its exchanges are no-ops) must reproduce the plain loop;
     the multi-rank exchanges themselves are covered over gloo in tests/test_cbet_model.py."""
@@ -267,6 +304,7 @@ def test_slab_owned_loop_on_one_rank_equals_the_plain_loop(api, setup, torch_cud
     assert r1["converged"] and r2["converged"] and r1["passes"] == r2["passes"]
     assert parity_err(e2.cpu().numpy(), e1.cpu().numpy()) < 1e-9
     assert np.abs(r1["beam_gain"] - r2["beam_gain"]).max() < 1e-9 * np.abs(r1["beam_gain"]).max()
+    assert r2["workspace_bytes"] == api.cbet_slab_workspace_bytes(tr.params, 1, 0) - 8 * (2 + api.MAX_CBET_BEAMS)
 
 
 def test_config3_cbet_solve_256_properties(api, inputs, torch_cuda):
