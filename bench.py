@@ -147,7 +147,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=256, help="grid nodes per axis (BASELINE config 3: 256)")
+    ap.add_argument("--n", "--grid", dest="n", type=int, default=256, help="grid nodes per axis (BASELINE config 3: 256)")
     ap.add_argument("--variant", type=int, default=0, help="cbet_params.kernel_variant (0 = default)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank flow on a 1-GPU box together with CBET_BENCH_DEVICE)")

@@ -5,15 +5,20 @@
 //   * rays are split across devices as interleaved ray bundles (every device sees every beam),
 //     not as contiguous blocks of nbeams/nGPUs beams (launch_ray_XZ.cu:123), so 60 beams on 8
 //     devices lose nothing to integer division and the load is even;
-//   * the per-device grids are summed on the devices by one RCCL all-reduce over xGMI, replacing
-//     the D2H copies and the host += loop (main.cu:178-210).  Device 0's copy of the sum is then
-//     ADDED into the caller's host grid, keeping rayTracing()'s "edep +=" contract.
+//   * the per-device grids are summed on the devices by one RCCL reduce-scatter over xGMI into x-slabs
+//     (half the traffic of an all-reduce), and every device then copies ITS slab to the host over its own
+//     PCIe link, in parallel, where its host thread ADDS it into the caller's grid -- replacing the serial
+//     whole-grid D2H copies and the host += loop (main.cu:178-210) and keeping rayTracing()'s "edep +="
+//     contract.  Communicators are created once per device set and cached for the life of the process.
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -32,13 +37,32 @@ double now_s()
     return std::chrono::duration<double>(clk::now().time_since_epoch()).count();
 }
 
+// RCCL communicators per ordered device set, created on first use and kept (ncclCommInitAll costs tens of
+// milliseconds -- more than a whole 256^3 pass).
+std::mutex g_comm_mu;
+std::map<std::vector<int>, std::vector<ncclComm_t>> g_comms;
+
+ncclResult_t communicators(const std::vector<int> &devs, std::vector<ncclComm_t> **out)
+{
+    std::lock_guard<std::mutex> lk(g_comm_mu);
+    auto it = g_comms.find(devs);
+    if (it == g_comms.end()) {
+        std::vector<ncclComm_t> c(devs.size());
+        const ncclResult_t r = ncclCommInitAll(c.data(), (int)devs.size(), devs.data());
+        if (r != ncclSuccess) return r;
+        it = g_comms.emplace(devs, std::move(c)).first;
+    }
+    *out = &it->second;
+    return ncclSuccess;
+}
+
 struct DeviceJob {
     int gpu = 0;
     int rc = CBET_OK;
     std::string err;
     cbet_context *ctx = nullptr;
     double *d_beam_norm = nullptr, *d_bbeam_norm = nullptr, *d_pow_r = nullptr, *d_phase_r = nullptr;
-    double *d_ne = nullptr, *d_te = nullptr, *d_r = nullptr, *d_edep = nullptr;
+    double *d_ne = nullptr, *d_te = nullptr, *d_r = nullptr, *d_edep = nullptr, *d_slab = nullptr;
     hipStream_t stream = nullptr;
     cbet_counters counters{};
 };
@@ -56,7 +80,7 @@ void release(DeviceJob &j)
     if (hipSetDevice(j.gpu) == hipSuccess) {
         if (j.stream) (void)hipStreamDestroy(j.stream);
         cbet_context_destroy(j.ctx);
-        for (double *p : {j.d_beam_norm, j.d_bbeam_norm, j.d_pow_r, j.d_phase_r, j.d_ne, j.d_te, j.d_r, j.d_edep})
+        for (double *p : {j.d_beam_norm, j.d_bbeam_norm, j.d_pow_r, j.d_phase_r, j.d_ne, j.d_te, j.d_r, j.d_edep, j.d_slab})
             if (p) (void)hipFree(p);
     }
     (void)hipGetLastError();  // a device that never existed must not leave a sticky error behind
@@ -96,10 +120,21 @@ extern "C" int cbet_ray_tracing(const double *te_profile, const double *r_profil
     cbet_host_power_table(phase_r.data(), pow_r.data());
     cbet_host_beam_trig(beam_norm, p->nbeams, bbeam.data());
 
-    const size_t edep_bytes = sizeof(double) * (size_t)d.edep_size;
+    // the device grids are padded to a whole number of x-planes per device, so that the reduce-scatter hands
+    // every device an equal slab (the padding planes stay zero)
+    const size_t plane = (size_t)(p->ny + 2) * (p->nz + 2);
+    const size_t slab_planes = ((size_t)p->nx + 2 + ngpu - 1) / ngpu, slab_elems = slab_planes * plane;
+    const size_t edep_bytes = sizeof(double) * slab_elems * ngpu;
     const size_t nr = (size_t)p->nprofile;
     std::vector<DeviceJob> jobs(ngpu);
     for (int i = 0; i < ngpu; ++i) jobs[i].gpu = gpus ? gpus[i] : i;
+    {
+        std::vector<int> sorted(ngpu);
+        for (int i = 0; i < ngpu; ++i) sorted[i] = jobs[i].gpu;
+        std::sort(sorted.begin(), sorted.end());
+        if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end())
+            return cbet::fail(CBET_EINVAL, "cbet_ray_tracing: a device is listed twice (one rank per device)");
+    }
 
     // main.cu:133-152: allocate + upload per device (plus the workspace, and a zeroed grid: the
     // reference accumulates into memory it never clears)
@@ -113,6 +148,7 @@ extern "C" int cbet_ray_tracing(const double *te_profile, const double *r_profil
         note(j, cbet_safeGPUAlloc((void **)&j.d_te, sizeof(double) * nr, g));
         note(j, cbet_safeGPUAlloc((void **)&j.d_r, sizeof(double) * nr, g));
         note(j, cbet_safeGPUAlloc((void **)&j.d_edep, edep_bytes, g));
+        if (ngpu > 1) note(j, cbet_safeGPUAlloc((void **)&j.d_slab, sizeof(double) * slab_elems, g));
         if (j.rc) return;
         note(j, cbet_moveToAndFromGPU(j.d_beam_norm, (void *)beam_norm, sizeof(double) * 3 * p->nbeams, g));
         note(j, cbet_moveToAndFromGPU(j.d_bbeam_norm, bbeam.data(), sizeof(double) * 4 * p->nbeams, g));
@@ -172,37 +208,52 @@ extern "C" int cbet_ray_tracing(const double *te_profile, const double *r_profil
     }
     const double t3 = now_s();
 
-    // Combine: RCCL all-reduce over xGMI (replaces main.cu:178-210), then "edep +=" on the host.
+    // Combine (replaces main.cu:178-210): RCCL reduce-scatter over xGMI into x-slabs, then every device's host
+    // thread copies its slab down its own PCIe link and adds it into the caller's grid ("edep +=", main.cu:206).
     int rc = CBET_OK;
     if (ngpu > 1) {
-        std::vector<ncclComm_t> comms(ngpu);
         std::vector<int> devs(ngpu);
         for (int i = 0; i < ngpu; ++i) devs[i] = jobs[i].gpu;
-        ncclResult_t nr_ = ncclCommInitAll(comms.data(), ngpu, devs.data());
+        std::vector<ncclComm_t> *comms = nullptr;
+        ncclResult_t nr_ = communicators(devs, &comms);
         if (nr_ != ncclSuccess) {
             rc = cbet::fail(CBET_ECOMM, "ncclCommInitAll: %s", ncclGetErrorString(nr_));
         } else {
             ncclGroupStart();
             for (int i = 0; i < ngpu && nr_ == ncclSuccess; ++i) {
                 (void)hipSetDevice(jobs[i].gpu);
-                nr_ = ncclAllReduce(jobs[i].d_edep, jobs[i].d_edep, (size_t)d.edep_size, ncclDouble, ncclSum,
-                                    comms[i], jobs[i].stream);
+                nr_ = ncclReduceScatter(jobs[i].d_edep, jobs[i].d_slab, slab_elems, ncclDouble, ncclSum, (*comms)[i],
+                                        jobs[i].stream);
             }
-            ncclResult_t ge = ncclGroupEnd();
+            const ncclResult_t ge = ncclGroupEnd();
             if (nr_ == ncclSuccess) nr_ = ge;
-            for (int i = 0; i < ngpu; ++i) {
-                (void)hipSetDevice(jobs[i].gpu);
-                (void)hipStreamSynchronize(jobs[i].stream);
-            }
-            if (nr_ != ncclSuccess) rc = cbet::fail(CBET_ECOMM, "ncclAllReduce: %s", ncclGetErrorString(nr_));
-            for (auto &c : comms) ncclCommDestroy(c);
+            if (nr_ != ncclSuccess) rc = cbet::fail(CBET_ECOMM, "ncclReduceScatter: %s", ncclGetErrorString(nr_));
         }
     }
     if (rc == CBET_OK) {
-        std::vector<double> staging((size_t)d.edep_size);
-        rc = cbet_moveToAndFromGPU(staging.data(), jobs[0].d_edep, edep_bytes, jobs[0].gpu);
-        if (rc == CBET_OK)
-            for (long i = 0; i < d.edep_size; ++i) edep[i] += staging[i];  // main.cu:206
+        auto fetch = [&](DeviceJob &j, int index) {
+            // slab `index` = planes [index * slab_planes, ...) of the haloed grid, clipped to nx + 2
+            const size_t first = (size_t)index * slab_planes;
+            const size_t planes_here = first >= (size_t)p->nx + 2 ? 0 : std::min(slab_planes, (size_t)p->nx + 2 - first);
+            if (planes_here == 0) return;
+            const size_t n = planes_here * plane;
+            std::vector<double> staging(n);
+            (void)hipSetDevice(j.gpu);
+            const double *src = ngpu > 1 ? j.d_slab : j.d_edep;
+            if (hipMemcpyAsync(staging.data(), src, n * sizeof(double), hipMemcpyDeviceToHost, j.stream) != hipSuccess ||
+                hipStreamSynchronize(j.stream) != hipSuccess) {
+                j.rc = CBET_EHIP;
+                j.err = "slab copy to the host failed";
+                (void)hipGetLastError();
+                return;
+            }
+            double *dst = edep + first * plane;
+            for (size_t i = 0; i < n; ++i) dst[i] += staging[i];   // main.cu:206, slabs are disjoint
+        };
+        std::vector<std::thread> th;
+        for (int i = 0; i < ngpu; ++i) th.emplace_back(fetch, std::ref(jobs[i]), i);
+        for (auto &t : th) t.join();
+        rc = first_error();
     }
     if (counters) {
         std::memset(counters, 0, sizeof *counters);

@@ -59,7 +59,6 @@ struct Origin {
     int x, y, z;
 };
 
-__device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
 // absolute coordinate in [o, o + 8) (or [o, o + WZ)) whose residue is r
 __device__ __forceinline__ int abs8(int o, int r) { return o + ((r - o) & 7); }

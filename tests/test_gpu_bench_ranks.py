@@ -1,0 +1,30 @@
+"""bench.py's N > 1 flow on the one-GPU box: two ranks share GPU 0 and gloo carries the combine (RCCL needs a device
+per rank), so the numbers mean nothing -- what is checked is the contract: the pipelined passes of both ranks add
+up to the whole workload, the reduce-scattered slabs add up to the known deposited total, one JSON line from rank 0."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_rank_bench_rehearsal():
+    port = 29950 + (os.getpid() % 40)
+    env = dict(os.environ, CBET_BENCH_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--grid", "64",
+           "--steps", "3", "--warmup", "1", "--no-cbet", "--no-cpu-baseline"]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert run.returncode == 0, run.stdout[-1500:] + run.stderr[-1500:]
+    lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "strong" and out["unit"] == "ray-steps/s"
+    assert out["config"]["ray_steps_per_pass"] == 30712072                      # SURVEY.md 8(c), 64^3: both ranks' shares
+    assert out["config"]["edep_sum"] == pytest.approx(6.1070952143e17, rel=1e-9)   # the slabs of the last pass, all ranks
+    assert out["value"] > 0 and out["roofline"]["kernel_ms"] > 0

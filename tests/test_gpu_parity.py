@@ -477,8 +477,18 @@ def test_orchestrator_fails_cleanly_without_enough_devices(api, inputs, torch_cu
     assert float(np.abs(edep).sum()) == 0.0              # nothing was added on failure
     with pytest.raises(api.CbetError):
         api.ray_tracing(te, r, ne, edep, p, beam_norm=bn[:2], gpus=[-1])
+    with pytest.raises(api.CbetError) as ei:             # one rank per device: RCCL cannot pair a device with itself
+        api.ray_tracing(te, r, ne, edep, p, beam_norm=bn[:2], gpus=[0, 0])
+    assert ei.value.code == api.EINVAL and float(np.abs(edep).sum()) == 0.0
     timers, cnt = api.ray_tracing(te, r, ne, edep, p, beam_norm=bn[:2], gpus=[0])
     assert cnt.ray_steps > 0 and edep.sum() > 0
+    # the CLI takes the same path: --gpus beyond the box is an error message and a non-zero exit, not a crash
+    import subprocess
+    from cbet_raytracing_3d_amd import build
+    from conftest import ROOT
+    out = subprocess.run([build.CLI_PATH, "10", "--n", "24", "--beams", "2", "--gpus", str(ndev + 1)], cwd=ROOT,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and ("hipSetDevice" in out.stderr or "device" in out.stderr.lower())
 
 
 def test_native_wide_index_grid_832(api, inputs, torch_cuda):
