@@ -34,18 +34,18 @@
 namespace cbet {
 namespace {
 
-template <int WZ_>
+template <int WZ_, bool PAD = true>
 struct Tile {
     static constexpr int W = 8;                 // x and y extent (nodes)
     static constexpr int WZ = WZ_;              // z extent
     static constexpr int ZM = WZ - 1;
     // Padded layout (doubles): ds_add_f64 costs the CU ~8 cycles when the lanes' addresses fall on different
     // bank pairs, +2 per lane sharing a bank, +3 per lane sharing an address (scripts/ubench/lds_atomic.hip),
-    // and a bundle's footprint is a few nodes wide per axis, so rows and planes are padded.
-    // The strides are chosen so that the 27 nodes of any 3 x 3 x 3 block fall on 27 different bank pairs for WZ = 16
-    // ((149 dx + 18 dy + dz) mod 32 takes 27 distinct values); the smaller tile keeps the compact (9, 76) pair.
-    static constexpr int YS = WZ == 16 ? 18 : WZ + 1;
-    static constexpr int XS = WZ == 16 ? 149 : W * YS + 4;
+    // and a bundle's footprint is a few nodes wide per axis, so rows are padded by one entry and planes by four
+    // (the conflict-free pair (18, 149) for WZ = 16 measured no faster: the LDS is not what binds, and its extra
+    // 576 bytes cost a wavefront of occupancy).  PAD = false: the dense layout, for the rarely used second box.
+    static constexpr int YS = PAD ? WZ + 1 : WZ;
+    static constexpr int XS = PAD ? W * YS + 4 : W * WZ;
     static constexpr int N = W * XS;            // doubles per tile
     static constexpr int S = W - 2;             // largest x / y offset of a lane's low corner inside the box
     static constexpr int SZ = WZ - 2;           // ... z offset
@@ -78,12 +78,12 @@ struct WaveCounters {
 // in-order vmcnt on CDNA: an atomic issued before a load delays that load's data by the atomic's round trip),
 // or (DEFER = false) add them to HBM now.  A plane is 8 x WZ entries: WZ/8 per lane, z fastest across lanes,
 // so one wave instruction covers whole rows -- 64-B lines when the z origin is brick-aligned.
-template <int WZ, int AX, bool DEFER, int NC>
+template <int WZ, int AX, bool DEFER, int NC, bool PAD = true>
 __device__ __forceinline__ void retire_plane(const TraceArgs &a, double *tile, const Origin &o, int coord, int lane,
                                              double *edep, int sXh, int sYh, WaveCounters &wc, double (&dv)[2],
                                              int (&dn)[2], int coff, long gstride)
 {
-    using T = Tile<WZ>;
+    using T = Tile<WZ, PAD>;
     constexpr int IT = T::W * WZ / kWave;
     const int fixed = coord & 7;
 #pragma unroll
@@ -128,12 +128,12 @@ __device__ __forceinline__ void retire_plane(const TraceArgs &a, double *tile, c
 }
 
 // z, single planes (WZ = 8): the plane is 8 x 8 (x, y) entries, one per lane, each in its own 64-B line of HBM.
-template <int WZ, bool DEFER, int NC>
+template <int WZ, bool DEFER, int NC, bool PAD = true>
 __device__ __forceinline__ void retire_zplane(const TraceArgs &a, double *tile, const Origin &o, int coord, int lane,
                                               double *edep, int sXh, int sYh, WaveCounters &wc, double &dv, int &dn,
                                               int coff, long gstride)
 {
-    using T = Tile<WZ>;
+    using T = Tile<WZ, PAD>;
     const int r0 = lane >> 3, r1 = lane & 7, fixed = coord & T::ZM;
     const int slot = r0 * T::XS + r1 * T::YS + fixed;
     const int node = abs8(o.x, r0) * sXh + abs8(o.y, r1) * sYh + coord;
@@ -187,14 +187,14 @@ __device__ __forceinline__ void retire_zbrick(const TraceArgs &a, double *tile, 
 }
 
 // Everything a box still holds goes to HBM (wave end, or box B emptying).
-template <int WZ, int NC>
+template <int WZ, int NC, bool PAD = true>
 __device__ __forceinline__ void flush_box(const TraceArgs &a, double *tile, const Origin &o, int lane, double *edep,
                                           int sXh, int sYh, WaveCounters &wc, int coff, long gstride)
 {
     double dv[2];
     int dn[2];
     for (int t = 0; t < Tile<WZ>::W; ++t)
-        retire_plane<WZ, 0, false, NC>(a, tile, o, o.x + t, lane, edep, sXh, sYh, wc, dv, dn, coff, gstride);
+        retire_plane<WZ, 0, false, NC, PAD>(a, tile, o, o.x + t, lane, edep, sXh, sYh, wc, dv, dn, coff, gstride);
 }
 
 // Deferred plane sums of box A: x and y planes (WZ/8 entries per lane each) and, for WZ = 8, one z-plane entry.
@@ -232,7 +232,7 @@ __device__ __forceinline__ int follow_brick_axis(int r, unsigned long long mm)
 // that count for this box.  The decisions are taken first, as scalars; the planes that leave are then written
 // back and the origin is moved by plain scalar arithmetic outside every divergent region (so that it stays in
 // scalar registers).  Returns true when the origin moved.
-template <int WZ, bool DEFER, int NC>
+template <int WZ, bool DEFER, int NC, bool PAD = true>
 __device__ __forceinline__ bool follow_box(const TraceArgs &a, double *tile, Origin &o, unsigned long long mm, int lx,
                                            int ly, int lz, int lane, double *edep, int sXh, int sYh, WaveCounters &wc,
                                            Deferred &d, int coff, long gstride)
@@ -240,11 +240,11 @@ __device__ __forceinline__ bool follow_box(const TraceArgs &a, double *tile, Ori
     using T = Tile<WZ>;
     const int dx = follow_plane_axis(lx - o.x, mm, T::S);
     if (dx != 0)
-        retire_plane<WZ, 0, DEFER, NC>(a, tile, o, dx < 0 ? o.x + T::W - 1 : o.x, lane, edep, sXh, sYh, wc, d.vx, d.nx, coff, gstride);
+        retire_plane<WZ, 0, DEFER, NC, PAD>(a, tile, o, dx < 0 ? o.x + T::W - 1 : o.x, lane, edep, sXh, sYh, wc, d.vx, d.nx, coff, gstride);
     o.x += dx;
     const int dy = follow_plane_axis(ly - o.y, mm, T::S);
     if (dy != 0)
-        retire_plane<WZ, 1, DEFER, NC>(a, tile, o, dy < 0 ? o.y + T::W - 1 : o.y, lane, edep, sXh, sYh, wc, d.vy, d.ny, coff, gstride);
+        retire_plane<WZ, 1, DEFER, NC, PAD>(a, tile, o, dy < 0 ? o.y + T::W - 1 : o.y, lane, edep, sXh, sYh, wc, d.vy, d.ny, coff, gstride);
     o.y += dy;
     int dz;
     if (T::BRICK) {
@@ -253,7 +253,7 @@ __device__ __forceinline__ bool follow_box(const TraceArgs &a, double *tile, Ori
     } else {
         dz = follow_plane_axis(lz - o.z, mm, T::SZ);
         if (dz != 0)
-            retire_zplane<WZ, DEFER, NC>(a, tile, o, dz < 0 ? o.z + WZ - 1 : o.z, lane, edep, sXh, sYh, wc, d.vz, d.nz, coff, gstride);
+            retire_zplane<WZ, DEFER, NC, PAD>(a, tile, o, dz < 0 ? o.z + WZ - 1 : o.z, lane, edep, sXh, sYh, wc, d.vz, d.nz, coff, gstride);
     }
     o.z += dz;
     const bool moved = (dx | dy | dz) != 0;
@@ -291,7 +291,7 @@ template <int WZ, bool GENERIC, int CBET>
 __global__ void __launch_bounds__(kWave) k_trace_window(const TraceArgs a)
 {
     using T = Tile<WZ>;            // box A
-    using TB = Tile<8>;            // box B holds the few lanes that left A: single z-planes, half the LDS
+    using TB = Tile<8, false>;     // box B holds the few lanes that left A: single z-planes, dense layout, under half the LDS
     constexpr int WZB = 8;
     constexpr bool IDX64 = GENERIC;
     constexpr int NC = (CBET == 4) ? 4 : 1;
@@ -532,44 +532,46 @@ __global__ void __launch_bounds__(kWave) k_trace_window(const TraceArgs a)
                 // box A follows the lanes whose home it is
                 bool moved = follow_box<WZ, true, NC>(a, tileA, oA, memA, lx, ly, lz, lane, edep, sXh, sYh, wc, dfr, NSLOT, a.comp_stride);
                 dfr_pending = dfr_pending || moved;
-                const bool inA = alive && holds<WZ>(oA, lx, ly, lz);
-                bool inB = false;
-                if (b_active) {  // scalar branch
-                    Deferred unused;
-                    moved = follow_box<WZB, false, 1>(a, tileB, oB, memB, lx, ly, lz, lane, edep, sXh, sYh, wc, unused, 0, 0) || moved;
-                    inB = alive && holds<WZB>(oB, lx, ly, lz);
-                }
-                // lanes that fell out of A look for a home in B; an idle B is re-created around the first of them
-                const bool lost = alive && !homeB && !inA;
-                const unsigned long long lost_mask = CBET_BALLOT(lost);
-                if (lost_mask != 0ull) {
-                    if (!b_active) {
+                const unsigned long long lost_mask =
+                    memA & ~(CBET_BALLOT((unsigned)(lx - oA.x) <= (unsigned)T::S) & CBET_BALLOT((unsigned)(ly - oA.y) <= (unsigned)T::S) &
+                             CBET_BALLOT((unsigned)(lz - oA.z) <= (unsigned)T::SZ));
+                if (lost_mask == 0ull && !b_active) {
+                    // the usual outcome: A moved and holds every live lane again (inbox = alive, tile_off = 0 stand)
+                    deep = box_deep_inside<WZ>(oA, nx, ny, nz);
+                } else {
+                    const bool inA = alive && holds<WZ>(oA, lx, ly, lz);
+                    const bool lost = alive && !homeB && !inA;
+                    // lanes that fell out of A look for a home in B, which follows its own lanes only (letting it chase the
+                    // lost ones as well was measured: more misses, 0.63 % against 0.48 % of the ray-steps); an idle B is
+                    // re-created around the first lost lane
+                    if (b_active) {  // scalar branch
+                        Deferred unused;
+                        follow_box<WZB, false, 1, false>(a, tileB, oB, memB, lx, ly, lz, lane, edep, sXh, sYh, wc, unused, 0, 0);
+                    } else if (lost_mask != 0ull) {
                         const int src = __ffsll((long long)lost_mask) - 1;
-                        oB.x = __builtin_amdgcn_readlane(lx, src) - (T::W / 2 - 1);
-                        oB.y = __builtin_amdgcn_readlane(ly, src) - (T::W / 2 - 1);
+                        oB.x = __builtin_amdgcn_readlane(lx, src) - (TB::W / 2 - 1);
+                        oB.y = __builtin_amdgcn_readlane(ly, src) - (TB::W / 2 - 1);
                         oB.z = __builtin_amdgcn_readlane(lz, src) - 3;
                         b_active = true;  // its tile is all zero: zeroed at start and flushed whenever it empties
-                        inB = alive && holds<WZB>(oB, lx, ly, lz);
                     }
+                    const bool inB = alive && holds<WZB>(oB, lx, ly, lz);
                     homeB = homeB || (lost && inB);
-                }
-                if (b_active) {
                     // a B lane that drifted out of B but back into A goes home
                     if (alive && homeB && !inB && inA) homeB = false;
                     hbm = CBET_BALLOT(alive && homeB);
                     if (hbm == 0ull) {
                         __builtin_amdgcn_wave_barrier();
-                        flush_box<WZB, 1>(a, tileB, oB, lane, edep, sXh, sYh, wc, 0, 0);
+                        flush_box<WZB, 1, false>(a, tileB, oB, lane, edep, sXh, sYh, wc, 0, 0);
                         b_active = false;
                     }
+                    __builtin_amdgcn_wave_barrier();
+                    const bool useB = alive && homeB && inB;
+                    inbox = useB || (alive && !homeB && inA);
+                    tile_off = useB ? T::N : 0;
+                    const bool missed = CBET_BALLOT(alive && !inbox) != 0ull;
+                    if (missed) wc.steps_miss += 1u;
+                    deep = !missed && box_deep_inside<WZ>(oA, nx, ny, nz) && (!b_active || box_deep_inside<WZB>(oB, nx, ny, nz));
                 }
-                __builtin_amdgcn_wave_barrier();
-                const bool useB = alive && homeB && inB;
-                inbox = useB || (alive && !homeB && inA);
-                tile_off = useB ? T::N : 0;
-                const bool missed = CBET_BALLOT(alive && !inbox) != 0ull;
-                if (missed) wc.steps_miss += 1u;
-                deep = !missed && box_deep_inside<WZ>(oA, nx, ny, nz) && (!b_active || box_deep_inside<WZB>(oB, nx, ny, nz));
             } else if (!deep) {
                 deep = box_deep_inside<WZ>(oA, nx, ny, nz) && (!b_active || box_deep_inside<WZB>(oB, nx, ny, nz));
             }
@@ -673,7 +675,7 @@ __global__ void __launch_bounds__(kWave) k_trace_window(const TraceArgs a)
     if (!T::BRICK && dfr.vz != 0.0) global_add(a, &edep[dfr.nz], dfr.vz);
     __syncthreads();
     flush_box<WZ, NC>(a, tileA, oA, lane, edep, sXh, sYh, wc, NSLOT, a.comp_stride);
-    if (b_active) flush_box<WZB, 1>(a, tileB, oB, lane, edep, sXh, sYh, wc, 0, 0);
+    if (b_active) flush_box<WZB, 1, false>(a, tileB, oB, lane, edep, sXh, sYh, wc, 0, 0);
 
     if (CBET && a.beam_gain) {  // one fp64 atomic per wave
         double t = gained;

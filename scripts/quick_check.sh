@@ -11,6 +11,6 @@ python - "$OUT/bench.json" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1])); r = d["roofline"]
 print("ms/step %.2f kernel %.2f atomics/step %.3f miss %.4f moved/wstep %.3f Bsteps %.3f" % (d["ms_per_step"], r["kernel_ms"], r["global_atomics_per_ray_step"],
-      r["window_miss_ray_step_frac"], r["slabs_retired_per_wave_step"], r["window_too_narrow_wave_step_frac"]))
+      r["window_miss_ray_step_frac"], r["window_moves_per_wave_step"], r["box_b_live_wave_step_frac"]))
 PY
 if [ "${2:-}" = "pmc" ]; then bash scripts/pmc_quick.sh "$TAG/pmc" 2>&1 | tail -6; fi
