@@ -42,8 +42,8 @@ struct Tile {
     // Padded layout (doubles): ds_add_f64 costs the CU ~8 cycles when the lanes' addresses fall on different
     // bank pairs, +2 per lane sharing a bank, +3 per lane sharing an address (scripts/ubench/lds_atomic.hip),
     // and a bundle's footprint is a few nodes wide per axis, so rows are padded by one entry and planes by four
-    // (the conflict-free pair (18, 149) for WZ = 16 measured no faster: the LDS is not what binds, and its extra
-    // 576 bytes cost a wavefront of occupancy).  PAD = false: the dense layout, for the rarely used second box.
+    // (the conflict-free pair (18, 149) for WZ = 16 measured no faster: its extra 576 bytes cost occupancy).
+    // PAD = false: the dense layout, for the rarely used second box.
     static constexpr int YS = PAD ? WZ + 1 : WZ;
     static constexpr int XS = PAD ? W * YS + 4 : W * WZ;
     static constexpr int N = W * XS;            // doubles per tile
@@ -84,11 +84,12 @@ __device__ __forceinline__ void retire_plane(const TraceArgs &a, double *tile, c
                                              int (&dn)[2], int coff, long gstride)
 {
     using T = Tile<WZ, PAD>;
-    constexpr int IT = T::W * WZ / kWave;
+    constexpr int IT = (T::W * WZ + kWave - 1) / kWave;
     const int fixed = coord & 7;
 #pragma unroll
     for (int e = 0; e < IT; ++e) {
         const int idx = e * kWave + lane;
+        if (T::W * WZ < kWave && idx >= T::W * WZ) continue;
         const int r0 = idx / WZ, r1 = idx & T::ZM;
         int slot, node, slot_d;
         const int k = absz<WZ>(o.z, r1);
@@ -165,11 +166,11 @@ __device__ __forceinline__ void retire_zplane(const TraceArgs &a, double *tile, 
 
 // z, bricks (WZ = 16): the 8 planes [zb, zb + 8), zb a multiple of 8, leave together.  Eight wave instructions,
 // one per tile x index; lanes = (y, z), z fastest: every atomic request is one full 64-B line of HBM.
-template <int WZ>
+template <int WZ, bool PAD = true>
 __device__ __forceinline__ void retire_zbrick(const TraceArgs &a, double *tile, const Origin &o, int zb, int lane,
                                               double *edep, int sXh, int sYh, WaveCounters &wc)
 {
-    using T = Tile<WZ>;
+    using T = Tile<WZ, PAD>;
     const int ty = lane >> 3, kz = lane & 7;
     const int base_slot = ty * T::YS + ((zb + kz) & T::ZM);
     const int base_node = abs8(o.y, ty) * sYh + zb + kz;
@@ -249,7 +250,7 @@ __device__ __forceinline__ bool follow_box(const TraceArgs &a, double *tile, Ori
     int dz;
     if (T::BRICK) {
         dz = 8 * follow_brick_axis(lz - o.z, mm);
-        if (dz != 0) retire_zbrick<WZ>(a, tile, o, dz < 0 ? o.z + 8 : o.z, lane, edep, sXh, sYh, wc);
+        if (dz != 0) retire_zbrick<WZ, PAD>(a, tile, o, dz < 0 ? o.z + 8 : o.z, lane, edep, sXh, sYh, wc);
     } else {
         dz = follow_plane_axis(lz - o.z, mm, T::SZ);
         if (dz != 0)
@@ -288,11 +289,15 @@ constexpr double kNearTol = 0.5001;   // launch_ray_XZ.cu:132, the nearest-node 
 constexpr double kFarJump = 1.4998;   // relocate_deep_interior's validity bound on |f - cell|
 
 template <int WZ, bool GENERIC, int CBET>
-__global__ void __launch_bounds__(kWave) k_trace_window(const TraceArgs a)
+__global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(const TraceArgs a)
 {
     using T = Tile<WZ>;            // box A
-    using TB = Tile<8, false>;     // box B holds the few lanes that left A: single z-planes, dense layout, under half the LDS
-    constexpr int WZB = 8;
+    // Box B holds the few lanes that left A: four single z-planes in the dense layout, 2 KB.  Occupancy is what this
+    // latency-bound loop responds to (256^3 pass: 25.7 ms at 8 waves per CU, 21.9 at 11, 20.9 at 12, 19.3 at 14), and
+    // the LDS is what caps it: 8 z-planes for B (4 KB, 12 waves) halve the window misses (0.5 % against 1.0 % of the
+    // ray-steps) but cost more than they save; A needs its padding (dense: 40 LDS cycles per ds_add_f64, 27 ms).
+    constexpr int WZB = 4;
+    using TB = Tile<WZB, false>;
     constexpr bool IDX64 = GENERIC;
     constexpr int NC = (CBET == 4) ? 4 : 1;
     constexpr int NSLOT = T::N + TB::N;                   // box A, box B
@@ -551,7 +556,7 @@ __global__ void __launch_bounds__(kWave) k_trace_window(const TraceArgs a)
                         const int src = __ffsll((long long)lost_mask) - 1;
                         oB.x = __builtin_amdgcn_readlane(lx, src) - (TB::W / 2 - 1);
                         oB.y = __builtin_amdgcn_readlane(ly, src) - (TB::W / 2 - 1);
-                        oB.z = __builtin_amdgcn_readlane(lz, src) - 3;
+                        oB.z = __builtin_amdgcn_readlane(lz, src) - TB::SZ / 2;
                         b_active = true;  // its tile is all zero: zeroed at start and flushed whenever it empties
                     }
                     const bool inB = alive && holds<WZB>(oB, lx, ly, lz);
