@@ -776,7 +776,7 @@ int cbet_gain_field(double *fields, const double *ne3d, double *gain, double *sc
 
 static int gain_field_impl(double *fields, const double *ne3d, double *gain, double *scratch, double *change,
                            int hx_lo, int hx_hi, bool packed, const cbet_params *p, const cbet_gain_params *g,
-                           cbet_context *ctx, void *stream);
+                           cbet_context *ctx, void *stream, bool consume = false);
 
 int cbet_gain_field_slab(double *fields, const double *ne3d, double *gain, double *scratch, double *change,
                          int hx_lo, int hx_hi, const cbet_params *p, const cbet_gain_params *g,
@@ -805,7 +805,7 @@ size_t cbet_cbet_slab_workspace_bytes(const cbet_params *p, int world_size, int 
 
 static int gain_field_impl(double *fields, const double *ne3d, double *gain, double *scratch, double *change,
                            int hx_lo, int hx_hi, bool packed, const cbet_params *p, const cbet_gain_params *g,
-                           cbet_context *ctx, void *stream)
+                           cbet_context *ctx, void *stream, bool consume)
 {
     if (!ctx) return fail(CBET_EINVAL, "NULL context");
     if (int rc = validate(p)) return rc;
@@ -826,6 +826,7 @@ static int gain_field_impl(double *fields, const double *ne3d, double *gain, dou
     a.relax = g->relax;
     a.fields = fields; a.ne3d = ne3d ? ne3d : ctx->ne3d; a.gain = gain; a.scratch = scratch; a.change = change;
     a.hx_lo = hx_lo; a.hx_hi = hx_hi;
+    a.consume = (consume && scratch) ? 1 : 0;
     const long plane = (long)(p->ny + 2) * (p->nz + 2);
     a.store0 = packed ? (long)hx_lo * plane : 0;
     a.bstride = packed ? (long)(hx_hi - hx_lo) * plane : d.edep_size;
@@ -884,8 +885,9 @@ int cbet_cbet_solve(double *te_data_g, double *r_data_g, double *ne_data_g, doub
         pf.beam_lo = 0; pf.beam_hi = p->nbeams;
         cbet_params pd = *p;            // deposition pass: the caller's grid layout, every beam
         pd.beam_lo = 0; pd.beam_hi = p->nbeams;
+        // the fields are cleared once; every gain update hands them back zeroed (GainArgs.consume)
+        CBET_HIP(hipMemsetAsync(fields, 0, 4 * nb * hsize * sizeof(double), s));
         for (int pass = 0; pass < g->max_passes; ++pass) {
-            CBET_HIP(hipMemsetAsync(fields, 0, 4 * nb * hsize * sizeof(double), s));
             {
                 CbetHooks h;
                 h.gain = pass == 0 ? nullptr : gain; h.quantity = CBET_DEPOSIT_FIELDS; h.max_exponent = g->max_exponent;
@@ -894,7 +896,7 @@ int cbet_cbet_solve(double *te_data_g, double *r_data_g, double *ne_data_g, doub
                     return r;
             }
             CBET_HIP(hipMemsetAsync(change, 0, 2 * sizeof(double), s));
-            if (int r = cbet_gain_field(fields, nullptr, gain, scratch, change, p, g, ctx, stream)) return r;
+            if (int r = gain_field_impl(fields, nullptr, gain, scratch, change, 0, p->nx + 2, false, p, g, ctx, stream, true)) return r;
             double hc[2];
             CBET_HIP(hipMemcpyAsync(hc, change, sizeof hc, hipMemcpyDeviceToHost, s));
             CBET_HIP(hipStreamSynchronize(s));

@@ -113,6 +113,7 @@ struct GainArgs {
     double *change;                         // device {sum |new-old|, sum |new|} accumulators, or NULL
     int hx_lo, hx_hi;                       // planes [hx_lo, hx_hi) of the haloed grid to update (a rank's slab; 0 .. nx+2 = all)
     // storage of fields / gain / scratch: entry of cell h of beam b at [b * bstride + h - store0] (+ component * nbeams * bstride)
+    int consume;                            // symmetric kernel: leave the fields zeroed instead of normalised (the solve loop's next pass accumulates into them)
     long store0, bstride;                   // whole-grid arrays: 0, hsize; slab-packed arrays: hx_lo * (ny+2)(nz+2), slab entries
 };
 

@@ -201,7 +201,12 @@ __global__ void __launch_bounds__(256) k_gain_field_sym(const GainArgs a)
             const long o = (long)b * hsize;
             const double E = valid ? fI[o] : 0.0;
             const bool pres = E > 0.0;
-            if (__builtin_amdgcn_ballot_w64(pres) == 0ull) continue;
+            if (__builtin_amdgcn_ballot_w64(pres) == 0ull) {
+                // a beam absent from the whole brick; consume: clear what little the deposit weights' negative
+                // fringe may have left here (see the end of the brick)
+                if (a.consume && E != 0.0) { fI[o] = 0.0; fx[o] = 0.0; fy[o] = 0.0; fz[o] = 0.0; }
+                continue;
+            }
             mask |= 1ull << b;
             if (valid) raw[o] = 0.0;
             if (pres) {
@@ -283,6 +288,16 @@ __global__ void __launch_bounds__(256) k_gain_field_sym(const GainArgs a)
                     sum_change += fabs(nw - old);
                     sum_abs += fabs(nw);
                 }
+        }
+        if (a.consume && valid) {
+            // consume: the fields have done their work -- hand them back zeroed, so that the next field pass can
+            // accumulate into them without a 33 GB memset in between (the lines were just written, they are in L2)
+            unsigned long long mz = mask;
+            while (mz != 0ull) {
+                const long o = (long)(__ffsll((long long)mz) - 1) * hsize;
+                mz &= mz - 1;
+                fI[o] = 0.0; fx[o] = 0.0; fy[o] = 0.0; fz[o] = 0.0;
+            }
         }
         if (valid) {  // beams absent from the whole brick relax towards zero
             unsigned long long rest = ~mask & (a.nbeams >= 64 ? ~0ull : ((1ull << a.nbeams) - 1));

@@ -30,8 +30,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        if "k_trace" not in k and "k_tabulate" not in k: continue
-        agg["k_trace" if "k_trace" in k else "k_tabulate"][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        if "k_trace" not in k and "k_tabulate" not in k and "k_step_table" not in k: continue
+        agg["k_trace" if "k_trace" in k else ("k_step_table" if "k_step_table" in k else "k_tabulate")][row["Counter_Name"]].append(float(row["Counter_Value"]))
 with open(out + "/summary.txt", "w") as fo:
     for k, d in agg.items():
         for c, v in sorted(d.items()):
