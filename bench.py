@@ -233,6 +233,10 @@ def main():
                        "rays_per_pass": 60 * int(d.nlive_rays), "kernel_variant": args.variant,
                        "sharding": "ray bundles interleaved over %d rank(s), %s" % (world, COMBINE_NOTE)},
             "roofline": roofline(traffic, steps_per_launch, kernel_s_rank, tot, steps_total),
+            "pipeline": {"passes_in_flight": 2, "traces_overlap": bool(pipe.overlap_traces),
+                         "note": "N > 1: consecutive passes' trace kernels run on separate streams and overlap (the drain of "
+                                 "one beside the head of the next), so roofline.kernel_ms there is a launch's stretched "
+                                 "duration, not the time it needs; N = 1 keeps one trace stream"},
         }
         if world == 1 and not args.no_cbet:
             pipe.close()

@@ -46,7 +46,7 @@ class Params(C.Structure):
         ("shard_index", C.c_int), ("shard_count", C.c_int),
         ("kernel_variant", C.c_int), ("force_wide_index", C.c_int),
         ("per_beam_grids", C.c_int), ("patch_order", C.c_int),
-        ("grid_beam0", C.c_int), ("grid_beams", C.c_int), ("order_phases", C.c_int),
+        ("grid_beam0", C.c_int), ("grid_beams", C.c_int),
     ]
 
     def copy(self, **overrides):
@@ -244,18 +244,14 @@ def live_ray_list(p):
 
 def shard_items(p, nbeams_local, shard_index, shard_count):
     """Host-side statement of the kernel's work split: the (beam_local, thread-ray id) pairs that
-    shard `shard_index` of `shard_count` traces (bundle g -> shard g % shard_count)."""
+    shard `shard_index` of `shard_count` traces (a contiguous near-equal part of the beam-major bundle list)."""
     live = live_ray_list(p)
     bpb = (len(live) + 63) // 64
     beams, ids = [], []
-    phases = p.order_phases if p.order_phases >= 1 else (2 if shard_count > 1 and p.patch_order != 0 else 1)
-    split = max(1, bpb // 3) if phases == 2 and bpb >= 3 else bpb      # cbet_phase_split
-    first = nbeams_local * split
-    for g in range(shard_index, nbeams_local * bpb, max(1, shard_count)):
-        if g < first:
-            b, k = g // split, g % split
-        else:
-            b, k = (g - first) // (bpb - split), split + (g - first) % (bpb - split)
+    total = nbeams_local * bpb
+    K, r = max(1, shard_count), (shard_index if shard_count > 1 else 0)
+    for g in range((r * total) // K, ((r + 1) * total) // K):
+        b, k = g // bpb, g % bpb
         chunk = live[64 * k: 64 * k + 64]
         chunk = chunk[chunk >= 0]
         beams.append(np.full(len(chunk), b, dtype=np.int32))

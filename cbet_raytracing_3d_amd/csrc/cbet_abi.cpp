@@ -121,13 +121,6 @@ static std::vector<double> launch_axis(int count, int denom_count, double half_c
     return t;
 }
 
-// patches of a beam that count as "long" in the two-phase order (api.shard_items mirrors this)
-static int phase_split_of(int bundles_per_beam)
-{
-    const int s = bundles_per_beam / 3;
-    return s < 1 ? bundles_per_beam : s;
-}
-
 static unsigned morton2(unsigned x, unsigned y)
 {
     auto spread = [](unsigned v) {
@@ -247,7 +240,6 @@ int cbet_params_default(cbet_params *p, int n)
     p->shard_count = 1;
     p->kernel_variant = CBET_KERNEL_DEFAULT;
     p->patch_order = 1;
-    p->order_phases = -1;
     return CBET_OK;
 }
 
@@ -610,12 +602,10 @@ static int trace_impl(int b, unsigned nindices, const double *ne3d, const double
     a.beam_lo = beam_lo; a.nbeams_local = beam_hi - beam_lo;
     a.bundles_per_beam = (ctx->nlive + kWave - 1) / kWave;
     a.total_bundles = (long)a.nbeams_local * a.bundles_per_beam;
-    a.shard_index = p->shard_count > 1 ? p->shard_index : 0;
-    a.shard_count = p->shard_count > 1 ? p->shard_count : 1;
-    {   // work-item order (cbet_params.order_phases)
-        const int phases = p->order_phases < 1 ? (a.shard_count > 1 && p->patch_order != 0 ? 2 : 1) : p->order_phases;
-        if (phases > 2) return fail(CBET_EINVAL, "order_phases must be -1 (auto), 1 or 2");
-        a.phase_split = phases == 2 ? phase_split_of(a.bundles_per_beam) : a.bundles_per_beam;
+    {   // this launch's share: a contiguous, near-equal part of the list (cbet_params.shard_index / shard_count)
+        const long K = p->shard_count > 1 ? p->shard_count : 1, r = p->shard_count > 1 ? p->shard_index : 0;
+        a.first_item = (r * a.total_bundles) / K;
+        a.item_count = ((r + 1) * a.total_bundles) / K - a.first_item;
     }
     a.ne3d = ne3d ? ne3d : ctx->ne3d;
     a.kap3d = kappa3d ? kappa3d : ctx->kap3d;

@@ -75,8 +75,7 @@ struct TraceArgs {
     // work split
     int beam_lo, nbeams_local, bundles_per_beam;
     long total_bundles;
-    int shard_index, shard_count;
-    int phase_split;                        // work-item order: patches [0, phase_split) of every beam first, then the rest (bundles_per_beam: one phase)
+    long first_item, item_count;            // this launch's contiguous share of the (beam, patch) list
     // tables
     const double *ne3d, *kap3d;
     const StepRecord *steprec;              // LDS_WINDOW kernel: per-node step records built from the two tables

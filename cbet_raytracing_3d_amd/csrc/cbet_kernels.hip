@@ -396,7 +396,7 @@ hipError_t launch_trace(const TraceArgs &a0, int variant, bool force_idx64, hipS
     }
 #endif
     if (variant == CBET_KERNEL_LDS_WINDOW) return launch_trace_window(a, force_idx64, stream);
-    const long waves = (a.total_bundles - a.shard_index + a.shard_count - 1) / a.shard_count;
+    const long waves = a.item_count;
     if (waves <= 0) return hipSuccess;
     const dim3 grid((unsigned)waves);
     if (variant == CBET_KERNEL_GLOBAL_ATOMICS) hipLaunchKernelGGL((k_trace_simple<1>), grid, dim3(kWave), 0, stream, a);

@@ -208,28 +208,18 @@ __device__ __forceinline__ double phi_det(double x)
     return p;
 }
 
-// The work item of workgroup `w` of a launch: which (beam, patch) bundle.  Beam-major: consecutive workgroups
-// are neighbouring patches of one beam and share table lines in L2/MALL.  A beam's patches are listed longest
-// rays first; with phase_split < bundles_per_beam the launch runs in two phases -- every beam's first
-// phase_split patches (the long bundles), beam by beam, then every beam's remaining (short) ones -- so that a
-// SHORT launch (one rank's share of a sharded pass) ends on short bundles instead of waiting ~a bundle lifetime
-// for the last beam's long ones; a full-size launch keeps one phase (two cost it ~10 % in cache locality,
-// DESIGN.md 6.1).  Interleaved sharding: item g belongs to shard g % shard_count.
+// The work item of workgroup `w` of a launch: which (beam, patch) bundle.  The list is beam-major -- consecutive
+// workgroups are neighbouring patches of one beam and share table lines in L2/MALL -- with each beam's patches
+// longest rays first (a globally longest-first order and a patch-major order were measured 9-17 % slower).  A
+// shard is a CONTIGUOUS 1/shard_count of that list (first_item .. first_item + count): a rank then walks ~7.5
+// whole beams of the 60 and touches only their stretch of the 537 MB record table, where an interleaved split
+// makes every rank touch every beam's (one rank's 1/8 share: 3.2 ms contiguous, 3.4 ms interleaved).
 __device__ __forceinline__ bool work_item(const TraceArgs &a, long w, int &beam, int &patch)
 {
-    const long g = a.shard_index + (long)a.shard_count * w;
-    if (g >= a.total_bundles) return false;  // wave-uniform
-    const long first = (long)a.nbeams_local * a.phase_split;   // items of the first phase
-    int beam_local;
-    if (g < first) {
-        beam_local = (int)(g / a.phase_split);
-        patch = (int)(g - (long)beam_local * a.phase_split);
-    } else {
-        const int rest = a.bundles_per_beam - a.phase_split;
-        const long h = g - first;
-        beam_local = (int)(h / rest);
-        patch = a.phase_split + (int)(h - (long)beam_local * rest);
-    }
+    const long g = a.first_item + w;
+    if (w >= a.item_count) return false;  // wave-uniform
+    const int beam_local = (int)(g / a.bundles_per_beam);
+    patch = (int)(g - (long)beam_local * a.bundles_per_beam);
     beam = a.beam_lo + beam_local;
     return true;
 }

@@ -707,7 +707,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
 
 hipError_t launch_trace_window(const TraceArgs &a, bool force_idx64, hipStream_t stream)
 {
-    const long waves = (a.total_bundles - a.shard_index + a.shard_count - 1) / a.shard_count;
+    const long waves = a.item_count;
     if (waves <= 0) return hipSuccess;
     const dim3 grid((unsigned)waves), block(kWave);
     // the step records are addressed with 64 bits always; GENERIC is needed for bookkeeping mode and, with the CBET

@@ -159,7 +159,7 @@ class RayTracer:
 
 
 def shard_of_rank(rank, world_size):
-    """(shard_index, shard_count) of a rank: bundle g belongs to rank g % world_size."""
+    """(shard_index, shard_count) of a rank: rank r traces the r-th contiguous 1/world_size of the bundle list."""
     if not 0 <= rank < world_size:
         raise ValueError("rank outside [0, world_size)")
     return rank, world_size
@@ -205,17 +205,23 @@ class SweepPipeline:
 
     Per pass k, with two alternating buffer sets b = k % 2 (deposition grid, node tables + step records = a
     second context):
-        prep stream  : [tables b free = trace k-2 done, grid b free = combine k-2 done]  zero grid b,
-                       tabulate the node tables, build the step records
-        trace stream : [prep k done]  trace this rank's share of the bundles into grid b, then enqueue the combine
-        RCCL stream  : reduce-scatter of grid b over xGMI (torch's process-group stream, async)
-    so pass k+1's preparation runs beside the drain of trace k (a launch's last half millisecond runs at low
-    occupancy: it cannot be shorter than one bundle's lifetime) and combine k runs beside trace k+1.  Replaces
+        prep stream b  : [tables b free = trace k-2 done, grid b free = combine k-2 done]  zero grid b,
+                         tabulate the node tables, build the step records
+        trace stream b : [prep k done]  trace this rank's share of the bundles into grid b, then enqueue the combine
+        RCCL stream    : reduce-scatter of grid b over xGMI (torch's process-group stream, async)
+    Nothing orders trace k+1 behind trace k (each buffer set has its own streams), so pass k+1's preparation AND the
+    head of its trace run beside the drain of trace k -- a launch's last half millisecond runs at low occupancy, it
+    cannot be shorter than one bundle's lifetime, and that is 0.8 ms of a 3.3 ms share at 8 ranks -- and combine k
+    runs beside trace k+1.  Replaces
     the serial launch -> D2H -> host sum of main.cu:166-210.  The combined result of a pass is slab r of the
     grid on rank r (reduce_scatter_grid)."""
 
-    def __init__(self, tracer, rank=0, world_size=1, group=None):
+    def __init__(self, tracer, rank=0, world_size=1, group=None, overlap_traces=None):
         self.tr, self.rank, self.world, self.group = tracer, rank, world_size, group
+        # a rank's share of a sharded pass is a short launch whose drain is a quarter of it: overlap consecutive
+        # traces there; a whole pass on one device gains 2 % and the kernel's own duration would no longer be
+        # what the events around it measure, so it keeps one trace stream
+        self.overlap_traces = (world_size > 1) if overlap_traces is None else bool(overlap_traces)
         p = tracer.params
         self.ctx = [tracer.ctx, api.Context(p, tracer.gpu)]
         planes = -(-(p.nx + 2) // world_size) * world_size          # padded to a multiple of the world size
@@ -223,7 +229,11 @@ class SweepPipeline:
         dev = tracer.device
         self.grids = [torch.zeros(shape, dtype=torch.float64, device=dev) for _ in range(2)]
         self.slabs = [torch.zeros((planes // world_size,) + shape[1:], dtype=torch.float64, device=dev) for _ in range(2)]
-        self.s_prep, self.s_trace = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        # one stream pair per buffer set: pass k+1 may start tracing while pass k is still draining
+        self.s_prep = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        self.s_trace = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        if not self.overlap_traces:
+            self.s_trace[1] = self.s_trace[0]
         self.ev_prep = [torch.cuda.Event() for _ in range(2)]
         self.ev_trace = [None, None]
         self.work = [None, None]
@@ -235,10 +245,10 @@ class SweepPipeline:
     def run_pass(self, timed=False):
         tr, d, b = self.tr, self.tr.derived, self.passes % 2
         self.passes += 1
-        with torch.cuda.stream(self.s_prep):
-            sp = self.s_prep.cuda_stream
+        with torch.cuda.stream(self.s_prep[b]):
+            sp = self.s_prep[b].cuda_stream
             if self.ev_trace[b] is not None:
-                self.s_prep.wait_event(self.ev_trace[b])
+                self.s_prep[b].wait_event(self.ev_trace[b])
             if self.work[b] is not None:
                 self.work[b].wait()            # this stream waits for combine k-2 before the grid is cleared
                 self.work[b] = None
@@ -246,9 +256,9 @@ class SweepPipeline:
             api.tabulate_plasma(self.ctx[b], self.launch_p, tr.d_te, tr.d_r, tr.d_ne, sp)
             api.prepare_step_records(self.ctx[b], self.launch_p, None, None, d.xconst, d.yconst, d.zconst, sp)
             self.ev_prep[b].record()
-        with torch.cuda.stream(self.s_trace):
-            st = self.s_trace.cuda_stream
-            self.s_trace.wait_event(self.ev_prep[b])
+        with torch.cuda.stream(self.s_trace[b]):
+            st = self.s_trace[b].cuda_stream
+            self.s_trace[b].wait_event(self.ev_prep[b])
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()

@@ -60,9 +60,9 @@ typedef struct cbet_params {
                                  /* beams [b*(nbeams/ngpus), (b+1)*(nbeams/ngpus)), as at      */
                                  /* launch_ray_XZ.cu:123                                       */
     int beam_lo, beam_hi;        /* explicit beam range [lo,hi) overriding the ngpus rule      */
-    int shard_index, shard_count;/* ray-bundle interleaved sharding inside the beam range:     */
-                                 /* bundle g is traced iff g % shard_count == shard_index      */
-                                 /* (shard_count<=1: everything)                               */
+    int shard_index, shard_count;/* ray-bundle sharding inside the beam range: the (beam, patch) */
+                                 /* list is cut into shard_count contiguous near-equal parts    */
+                                 /* and part shard_index is traced (shard_count<=1: everything) */
     int kernel_variant;          /* CBET_KERNEL_*                                              */
     int force_wide_index;        /* test hook: use the 64-bit node-table indexing path that grids  */
                                  /* with 8*nx*ny*nz >= 2^32 bytes (n > 812) need, at any size      */
@@ -77,11 +77,6 @@ typedef struct cbet_params {
                                  /* grid_beam0 + grid_beams): beam b uses grid b - grid_beam0.  grid_beams = 0 */
                                  /* (default): the arrays hold all nbeams grids.  This is how a rank of the    */
                                  /* slab-owned CBET loop keeps only ITS beams' fields and gain.                */
-    int order_phases;            /* work-item order: 1 = beam-major (beam by beam, each beam's patches in   */
-                                 /* list order); 2 = every beam's long bundles (the first third of its      */
-                                 /* list) first, then every beam's short ones, so that a short launch ends  */
-                                 /* on short bundles; -1 = auto: 2 for sharded launches (shard_count > 1),  */
-                                 /* 1 otherwise                                                              */
 } cbet_params;
 
 /* Quantities the reference derives in def.cuh / main.cu:156-161, evaluated in the same order. */
@@ -130,8 +125,8 @@ int cbet_derive(const cbet_params *p, cbet_derived *d);
  * section is cut into 8x8-ray patches (cbet_params.patch_order); 64 consecutive entries = one patch = one ray
  * bundle = one wavefront.  An entry is the thread-ray id (launch_ray_XZ.cu:125,156) of that ray,
  * or -1 for a hole: a ray the reference launch shape never visits or one that fails init()'s
- * beam-radius test (:94,114).  Work items g are (beam, patch) pairs in the order of
- * cbet_params.order_phases; item g is traced by shard g % shard_count.
+ * beam-radius test (:94,114).  Work items g are (beam, patch) pairs, beam by beam, patch by patch;
+ * shard s of K traces the items [s T / K, (s + 1) T / K) of the T in the list.
  * Writes min(n, cap) entries to out (may be NULL) and n to *count.
  */
 int cbet_live_ray_list(const cbet_params *p, int *out, long cap, long *count);

@@ -133,8 +133,16 @@ def test_shard_plan_partitions_the_work(api):
     allp = np.concatenate(seen)
     assert len(allp) == len(full_i)
     assert len({(int(a), int(b)) for a, b in allp}) == len(full_i)
-    sizes = [len(s) for s in seen]
-    assert max(sizes) - min(sizes) <= 0.05 * max(sizes)
+    # contiguous parts of the beam-major list: each shard's beams form a contiguous run, the shards are in list order
+    # and hold the same number of bundles to within one
+    bpb = (len(api.live_ray_list(p)) + 63) // 64
+    firsts = [int(s[0, 0]) for s in seen]
+    assert firsts == sorted(firsts) and all(np.all(np.diff(s[:, 0]) >= 0) for s in seen)
+    live = api.live_ray_list(p)
+    per_bundle = (live.reshape(-1, 64) >= 0).sum(1)
+    tiled = np.tile(per_bundle, nb)
+    T = nb * bpb
+    assert [len(s) for s in seen] == [int(tiled[(k * T) // 4:((k + 1) * T) // 4].sum()) for k in range(4)]
 
 
 def test_error_paths_without_a_gpu(api):

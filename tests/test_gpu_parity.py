@@ -547,11 +547,16 @@ def test_beam_resolved_deposition(api, oracle, inputs, torch_cuda, variant):
     for b in range(5):
         oe, _ = oracle.trace(cfg, bn[beams].copy(), r, ne, te, beam_lo=b, beam_hi=b + 1, nthreads=NCPU)
         assert parity_err(per[b], oe) < PARITY_TOL, b
-    # sharded + beam range: only the requested beams' grids are touched
+    # sharded + beam range: only the requested beams' grids are touched; the two contiguous halves of the (beam 1,
+    # beam 2) list are beam 1 and beam 2
     part = tr.new_grid(per_beam=True)
     tr.launch(part, kernel_variant=variant, beam_lo=1, beam_hi=3, shard_index=1, shard_count=2)
     part = part.cpu().numpy()
-    assert float(np.abs(part[[0, 3, 4]]).sum()) == 0.0 and part[1].sum() > 0 and part[2].sum() > 0
+    assert float(np.abs(part[[0, 1, 3, 4]]).sum()) == 0.0 and parity_err(part[2], per[2]) < 1e-11
+    part = tr.new_grid(per_beam=True)
+    tr.launch(part, kernel_variant=variant, beam_lo=1, beam_hi=3, shard_index=0, shard_count=3)   # 2/3 of beam 1
+    part = part.cpu().numpy()
+    assert float(np.abs(part[[0, 2, 3, 4]]).sum()) == 0.0 and 0 < part[1].sum() < per[1].sum()
     tr.close()
 
 
