@@ -148,6 +148,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n", "--grid", dest="n", type=int, default=256, help="grid nodes per axis (BASELINE config 3: 256)")
+    ap.add_argument("--rays-per-zone", type=int, default=4, help="def.cuh:58 ships 4; BASELINE config 5 as stated (1.13e6 ray "
+                    "ids per beam at 512^3) is 6")
     ap.add_argument("--variant", type=int, default=0, help="cbet_params.kernel_variant (0 = default)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank flow on a 1-GPU box together with CBET_BENCH_DEVICE)")
@@ -179,7 +181,8 @@ def main():
     n = args.n
     r, ne, te = api.load_s83177()
     bn = api.omega60_beam_norm()
-    p = api.default_params(n, kernel_variant=args.variant)
+    p = api.default_params(n, kernel_variant=args.variant, rays_per_zone=args.rays_per_zone)
+    workload = "omega60_%dcube_s83177_absorption" % n + ("" if args.rays_per_zone == 4 else "_rpz%d" % args.rays_per_zone)
     tr = RayTracer(p, r, ne, te, beam_norm=bn)
     d = tr.derived
     pipe = SweepPipeline(tr, rank, world)
@@ -219,7 +222,7 @@ def main():
 
     if rank == 0:
         steps_per_launch = steps_total / args.steps / world   # ray-steps one launch processes (avg rank)
-        traffic = measured_traffic("omega60_%dcube_s83177_absorption" % n, args.variant) if world == 1 else None
+        traffic = measured_traffic(workload, args.variant) if world == 1 else None
         achieved = steps_per_launch * BYTES_PER_RAY_STEP / kernel_s_rank
         out = {
             "metric": "ray-steps/sec, OMEGA 60-beam %d^3 sweep" % n,
@@ -227,11 +230,11 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed_max / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic (OMEGA-60 port table + s83177 ne/Te profile, deterministic)",
-            "config": {"workload": "omega60_%dcube_s83177_absorption" % n, "grid": n, "beams": 60,
+            "config": {"workload": workload, "grid": n, "beams": 60, "rays_per_zone": args.rays_per_zone,
                        "edep_sum": edep_sum, "backend": args.backend if world > 1 else None,
                        "ray_steps_per_pass": steps_total / args.steps,
                        "rays_per_pass": 60 * int(d.nlive_rays), "kernel_variant": args.variant,
-                       "sharding": "ray bundles interleaved over %d rank(s), %s" % (world, COMBINE_NOTE)},
+                       "sharding": "contiguous 1/%d parts of the beam-major ray-bundle list, %s" % (world, COMBINE_NOTE)},
             "roofline": roofline(traffic, steps_per_launch, kernel_s_rank, tot, steps_total),
             "pipeline": {"passes_in_flight": 2, "traces_overlap": bool(pipe.overlap_traces),
                          "note": "N > 1: consecutive passes' trace kernels run on separate streams and overlap (the drain of "

@@ -8,7 +8,6 @@ from cbet_raytracing_3d_amd.tracer import RayTracer
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 with_gain = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-two = int(sys.argv[4]) if len(sys.argv) > 4 else None   # lds_two_boxes override
 r, ne, te = api.load_s83177()
 tr = RayTracer(api.default_params(n), r, ne, te)
 gp = api.default_gain_params()
@@ -16,14 +15,14 @@ tr.tabulate()
 f = tr.new_fields()
 g = tr.new_grid(per_beam=True).fill_(1.0) if with_gain else None
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-tr.launch_cbet(f, gp, fields=True, gain=g, lds_two_boxes=two)
+tr.launch_cbet(f, gp, fields=True, gain=g)
 tr.counters(reset=True)
 a.record()
 for _ in range(reps):
-    tr.launch_cbet(f, gp, fields=True, gain=g, lds_two_boxes=two)
+    tr.launch_cbet(f, gp, fields=True, gain=g)
 b.record()
 torch.cuda.synchronize()
-print("field pass: %.2f ms (n=%d, gain=%d, lds_two_boxes=%s)" % (a.elapsed_time(b) / reps, n, with_gain, two))
+print("field pass: %.2f ms (n=%d, gain=%d)" % (a.elapsed_time(b) / reps, n, with_gain))
 c = tr.counters()
 print("ray-steps %d lane-atomics/step %.3f wave-steps %d miss-wave-step frac %.4f" %
       (c.ray_steps, c.global_atomics / c.ray_steps, c.wave_steps, c.wave_steps_miss / c.wave_steps))

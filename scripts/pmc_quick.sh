@@ -40,7 +40,7 @@ wc = m.get("SQ_WAVE_CYCLES", 1)
 print("wave time: waitcnt %4.1f%%  issue-stall %4.1f%% (LDS part %4.1f%%)  active %4.1f%%" % (
     100 * m.get("SQ_WAIT_ANY", 0) / wc, 100 * m.get("SQ_WAIT_INST_ANY", 0) / wc, 100 * m.get("SQ_WAIT_INST_LDS", 0) / wc,
     100 * m.get("SQ_ACTIVE_INST_ANY", 0) / wc))
-ws = m.get("SQ_INSTS_VMEM_RD", 0) / 7.0
+ws = m.get("SQ_INSTS_VMEM_RD", 0) / 2.33   # wave-steps: 2.33 vector loads per wave-step measured at 256^3 (record gather + launch / retire reads)
 print("per wave-step: VALU %.0f SALU %.0f LDS %.1f VMEM_WR %.2f" % (m.get("SQ_INSTS_VALU", 0) / ws, m.get("SQ_INSTS_SALU", 0) / ws,
       m.get("SQ_INSTS_LDS", 0) / ws, m.get("SQ_INSTS_VMEM_WR", 0) / ws))
 print("atomic requests %.3g x64B = %.3g GB  L2 hit %.0f%%" % (m.get("TCC_EA0_ATOMIC_sum", 0), 64e-9 * m.get("TCC_EA0_ATOMIC_sum", 0),
