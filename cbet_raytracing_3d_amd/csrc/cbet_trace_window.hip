@@ -34,36 +34,35 @@
 namespace cbet {
 namespace {
 
-template <int WZ_, bool PAD = true>
+// A wave-private tile of fp64 accumulators covering WX x WY x WZ nodes (powers of two), addressed toroidally.
+template <int WX_, int WY_, int WZ_, bool PAD>
 struct Tile {
-    static constexpr int W = 8;                 // x and y extent (nodes)
-    static constexpr int WZ = WZ_;              // z extent
-    static constexpr int ZM = WZ - 1;
+    static constexpr int WX = WX_, WY = WY_, WZ = WZ_;
+    static constexpr int XM = WX - 1, YM = WY - 1, ZM = WZ - 1;
     // Padded layout (doubles): ds_add_f64 costs the CU ~8 cycles when the lanes' addresses fall on different
     // bank pairs, +2 per lane sharing a bank, +3 per lane sharing an address (scripts/ubench/lds_atomic.hip),
     // and a bundle's footprint is a few nodes wide per axis, so rows are padded by one entry and planes by four
-    // (the conflict-free pair (18, 149) for WZ = 16 measured no faster: its extra 576 bytes cost occupancy).
+    // (the conflict-free pair (18, 149) for WZ = 16 measured no faster: its extra 576 bytes cost occupancy; the
+    // smaller (17, 136) and (16, 132) are 0.5 ms slower).
     // PAD = false: the dense layout, for the rarely used second box.
     static constexpr int YS = PAD ? WZ + 1 : WZ;
-    static constexpr int XS = PAD ? W * YS + 4 : W * WZ;
-    static constexpr int N = W * XS;            // doubles per tile
-    static constexpr int S = W - 2;             // largest x / y offset of a lane's low corner inside the box
-    static constexpr int SZ = WZ - 2;           // ... z offset
-    static constexpr bool BRICK = WZ == 16;     // z follows in aligned bricks of 8 planes
-    static constexpr int DT = W * W * WZ;       // unpadded component tile (CBET field pass)
-    static __device__ __forceinline__ int slot_d(int tx, int ty, int tz) { return (tx * W + ty) * WZ + tz; }
+    static constexpr int XS = PAD ? WY * YS + 4 : WY * WZ;
+    static constexpr int N = WX * XS;           // doubles per tile
+    // largest offset of a lane's low corner from the origin at which its two nodes still lie inside
+    static constexpr int SX = WX - 2, SY = WY - 2, SZ = WZ - 2;
+    static constexpr bool BRICK = WZ == 16 && WY == 8;   // z follows in aligned bricks of 8 planes (rows of 8 x 8 lanes)
+    static constexpr int DT = WX * WY * WZ;     // unpadded component tile (CBET field pass)
+    static __device__ __forceinline__ int slot_d(int tx, int ty, int tz) { return (tx * WY + ty) * WZ + tz; }
 };
 
-// Wave-uniform state of one box: origin = haloed index of its low corner; it covers [o, o+W) x [o, o+W) x [o, o+WZ).
+// Wave-uniform state of one box: origin = haloed index of its low corner; it covers [o, o+W) per axis.
 struct Origin {
     int x, y, z;
 };
 
-
-// absolute coordinate in [o, o + 8) (or [o, o + WZ)) whose residue is r
-__device__ __forceinline__ int abs8(int o, int r) { return o + ((r - o) & 7); }
-template <int WZ>
-__device__ __forceinline__ int absz(int o, int r) { return o + ((r - o) & (WZ - 1)); }
+// absolute coordinate in [o, o + M + 1) whose residue modulo M + 1 is r's
+template <int M>
+__device__ __forceinline__ int abs_in(int o, int r) { return o + ((r - o) & M); }
 
 struct WaveCounters {
     int n_atomics = 0;        // per lane
@@ -76,31 +75,32 @@ struct WaveCounters {
 // the non-zero ones and either hand them back in (dv, dn) -- value and flat haloed node -- so that the caller
 // can issue the global atomic LATER, behind the next step's gathers (loads, stores and atomics share one
 // in-order vmcnt on CDNA: an atomic issued before a load delays that load's data by the atomic's round trip),
-// or (DEFER = false) add them to HBM now.  A plane is 8 x WZ entries: WZ/8 per lane, z fastest across lanes,
-// so one wave instruction covers whole rows -- 64-B lines when the z origin is brick-aligned.
-template <int WZ, int AX, bool DEFER, int NC, bool PAD = true>
+// or (DEFER = false) add them to HBM now.  A plane is W x WZ entries (W = the other lateral extent), z fastest
+// across lanes, so one wave instruction covers whole rows -- 64-B lines when the z origin is brick-aligned.
+template <class T, int AX, bool DEFER, int NC>
 __device__ __forceinline__ void retire_plane(const TraceArgs &a, double *tile, const Origin &o, int coord, int lane,
                                              double *edep, int sXh, int sYh, WaveCounters &wc, double (&dv)[2],
                                              int (&dn)[2], int coff, long gstride)
 {
-    using T = Tile<WZ, PAD>;
-    constexpr int IT = (T::W * WZ + kWave - 1) / kWave;
-    const int fixed = coord & 7;
+    constexpr int WO = AX == 0 ? T::WY : T::WX;      // extent of the other lateral axis
+    constexpr int IT = (WO * T::WZ + kWave - 1) / kWave;
+    static_assert(IT <= 2, "a plane is at most two entries per lane");
+    const int fixed = coord & (AX == 0 ? T::XM : T::YM);
 #pragma unroll
     for (int e = 0; e < IT; ++e) {
         const int idx = e * kWave + lane;
-        if (T::W * WZ < kWave && idx >= T::W * WZ) continue;
-        const int r0 = idx / WZ, r1 = idx & T::ZM;
+        if (WO * T::WZ < kWave && idx >= WO * T::WZ) continue;
+        const int r0 = idx / T::WZ, r1 = idx & T::ZM;
         int slot, node, slot_d;
-        const int k = absz<WZ>(o.z, r1);
+        const int k = abs_in<T::ZM>(o.z, r1);
         if (AX == 0) {
             slot = fixed * T::XS + r0 * T::YS + r1;
             slot_d = T::slot_d(fixed, r0, r1);
-            node = coord * sXh + abs8(o.y, r0) * sYh + k;
+            node = coord * sXh + abs_in<T::YM>(o.y, r0) * sYh + k;
         } else {
             slot = r0 * T::XS + fixed * T::YS + r1;
             slot_d = T::slot_d(r0, fixed, r1);
-            node = abs8(o.x, r0) * sXh + coord * sYh + k;
+            node = abs_in<T::XM>(o.x, r0) * sXh + coord * sYh + k;
         }
         if (!CBET_AUDIT(a, (unsigned)slot < (unsigned)T::N)) continue;
         const double v = tile[slot];
@@ -128,16 +128,18 @@ __device__ __forceinline__ void retire_plane(const TraceArgs &a, double *tile, c
     }
 }
 
-// z, single planes (WZ = 8): the plane is 8 x 8 (x, y) entries, one per lane, each in its own 64-B line of HBM.
-template <int WZ, bool DEFER, int NC, bool PAD = true>
+// z, single planes (tiles without bricks): the plane is WX x WY (x, y) entries, at most one per lane, each in its
+// own 64-B line of HBM.
+template <class T, bool DEFER, int NC>
 __device__ __forceinline__ void retire_zplane(const TraceArgs &a, double *tile, const Origin &o, int coord, int lane,
                                               double *edep, int sXh, int sYh, WaveCounters &wc, double &dv, int &dn,
                                               int coff, long gstride)
 {
-    using T = Tile<WZ, PAD>;
-    const int r0 = lane >> 3, r1 = lane & 7, fixed = coord & T::ZM;
+    static_assert(T::WX * T::WY <= kWave, "one z-plane entry per lane");
+    if (T::WX * T::WY < kWave && lane >= T::WX * T::WY) return;
+    const int r0 = lane / T::WY, r1 = lane & T::YM, fixed = coord & T::ZM;
     const int slot = r0 * T::XS + r1 * T::YS + fixed;
-    const int node = abs8(o.x, r0) * sXh + abs8(o.y, r1) * sYh + coord;
+    const int node = abs_in<T::XM>(o.x, r0) * sXh + abs_in<T::YM>(o.y, r1) * sYh + coord;
     if (!CBET_AUDIT(a, (unsigned)slot < (unsigned)T::N)) return;
     const double v = tile[slot];
     if (NC > 1) {
@@ -164,41 +166,42 @@ __device__ __forceinline__ void retire_zplane(const TraceArgs &a, double *tile, 
     }
 }
 
-// z, bricks (WZ = 16): the 8 planes [zb, zb + 8), zb a multiple of 8, leave together.  Eight wave instructions,
-// one per tile x index; lanes = (y, z), z fastest: every atomic request is one full 64-B line of HBM.
-template <int WZ, bool PAD = true>
+// z, bricks (WZ = 16): the 8 planes [zb, zb + 8), zb a multiple of 8, leave together.  One wave instruction per
+// tile x index; lanes = (y, z), z fastest: every atomic request is one full 64-B line of HBM.
+template <class T>
 __device__ __forceinline__ void retire_zbrick(const TraceArgs &a, double *tile, const Origin &o, int zb, int lane,
                                               double *edep, int sXh, int sYh, WaveCounters &wc)
 {
-    using T = Tile<WZ, PAD>;
+    static_assert(T::WY == 8 && T::WZ == 16, "a brick is 8 rows of 8 planes per tile x index");
     const int ty = lane >> 3, kz = lane & 7;
     const int base_slot = ty * T::YS + ((zb + kz) & T::ZM);
-    const int base_node = abs8(o.y, ty) * sYh + zb + kz;
+    const int base_node = abs_in<T::YM>(o.y, ty) * sYh + zb + kz;
 #pragma unroll
-    for (int tx = 0; tx < T::W; ++tx) {
+    for (int tx = 0; tx < T::WX; ++tx) {
         const int slot = tx * T::XS + base_slot;
         if (!CBET_AUDIT(a, (unsigned)slot < (unsigned)T::N)) continue;
         const double v = tile[slot];
         if (v != 0.0) {
             tile[slot] = 0.0;
             ++wc.n_atomics;
-            global_add(a, &edep[abs8(o.x, tx) * sXh + base_node], v);
+            global_add(a, &edep[abs_in<T::XM>(o.x, tx) * sXh + base_node], v);
         }
     }
 }
 
 // Everything a box still holds goes to HBM (wave end, or box B emptying).
-template <int WZ, int NC, bool PAD = true>
+template <class T, int NC>
 __device__ __forceinline__ void flush_box(const TraceArgs &a, double *tile, const Origin &o, int lane, double *edep,
                                           int sXh, int sYh, WaveCounters &wc, int coff, long gstride)
 {
     double dv[2];
     int dn[2];
-    for (int t = 0; t < Tile<WZ>::W; ++t)
-        retire_plane<WZ, 0, false, NC, PAD>(a, tile, o, o.x + t, lane, edep, sXh, sYh, wc, dv, dn, coff, gstride);
+    for (int t = 0; t < T::WX; ++t)
+        retire_plane<T, 0, false, NC>(a, tile, o, o.x + t, lane, edep, sXh, sYh, wc, dv, dn, coff, gstride);
 }
 
-// Deferred plane sums of box A: x and y planes (WZ/8 entries per lane each) and, for WZ = 8, one z-plane entry.
+// Deferred plane sums of box A: x and y planes (at most two entries per lane each) and, for tiles without bricks,
+// one z-plane entry.
 struct Deferred {
     double vx[2] = {0.0, 0.0}, vy[2] = {0.0, 0.0}, vz = 0.0;
     int nx[2] = {0, 0}, ny[2] = {0, 0}, nz = 0;
@@ -233,28 +236,27 @@ __device__ __forceinline__ int follow_brick_axis(int r, unsigned long long mm)
 // that count for this box.  The decisions are taken first, as scalars; the planes that leave are then written
 // back and the origin is moved by plain scalar arithmetic outside every divergent region (so that it stays in
 // scalar registers).  Returns true when the origin moved.
-template <int WZ, bool DEFER, int NC, bool PAD = true>
+template <class T, bool DEFER, int NC>
 __device__ __forceinline__ bool follow_box(const TraceArgs &a, double *tile, Origin &o, unsigned long long mm, int lx,
                                            int ly, int lz, int lane, double *edep, int sXh, int sYh, WaveCounters &wc,
                                            Deferred &d, int coff, long gstride)
 {
-    using T = Tile<WZ>;
-    const int dx = follow_plane_axis(lx - o.x, mm, T::S);
+    const int dx = follow_plane_axis(lx - o.x, mm, T::SX);
     if (dx != 0)
-        retire_plane<WZ, 0, DEFER, NC, PAD>(a, tile, o, dx < 0 ? o.x + T::W - 1 : o.x, lane, edep, sXh, sYh, wc, d.vx, d.nx, coff, gstride);
+        retire_plane<T, 0, DEFER, NC>(a, tile, o, dx < 0 ? o.x + T::WX - 1 : o.x, lane, edep, sXh, sYh, wc, d.vx, d.nx, coff, gstride);
     o.x += dx;
-    const int dy = follow_plane_axis(ly - o.y, mm, T::S);
+    const int dy = follow_plane_axis(ly - o.y, mm, T::SY);
     if (dy != 0)
-        retire_plane<WZ, 1, DEFER, NC, PAD>(a, tile, o, dy < 0 ? o.y + T::W - 1 : o.y, lane, edep, sXh, sYh, wc, d.vy, d.ny, coff, gstride);
+        retire_plane<T, 1, DEFER, NC>(a, tile, o, dy < 0 ? o.y + T::WY - 1 : o.y, lane, edep, sXh, sYh, wc, d.vy, d.ny, coff, gstride);
     o.y += dy;
     int dz;
-    if (T::BRICK) {
+    if constexpr (T::BRICK) {
         dz = 8 * follow_brick_axis(lz - o.z, mm);
-        if (dz != 0) retire_zbrick<WZ, PAD>(a, tile, o, dz < 0 ? o.z + 8 : o.z, lane, edep, sXh, sYh, wc);
+        if (dz != 0) retire_zbrick<T>(a, tile, o, dz < 0 ? o.z + 8 : o.z, lane, edep, sXh, sYh, wc);
     } else {
         dz = follow_plane_axis(lz - o.z, mm, T::SZ);
         if (dz != 0)
-            retire_zplane<WZ, DEFER, NC, PAD>(a, tile, o, dz < 0 ? o.z + WZ - 1 : o.z, lane, edep, sXh, sYh, wc, d.vz, d.nz, coff, gstride);
+            retire_zplane<T, DEFER, NC>(a, tile, o, dz < 0 ? o.z + T::WZ - 1 : o.z, lane, edep, sXh, sYh, wc, d.vz, d.nz, coff, gstride);
     }
     o.z += dz;
     const bool moved = (dx | dy | dz) != 0;
@@ -262,21 +264,20 @@ __device__ __forceinline__ bool follow_box(const TraceArgs &a, double *tile, Ori
     return moved;
 }
 
-template <int WZ>
+template <class T>
 __device__ __forceinline__ bool holds(const Origin &o, int lx, int ly, int lz)
 {
-    return (unsigned)(lx - o.x) <= (unsigned)Tile<WZ>::S && (unsigned)(ly - o.y) <= (unsigned)Tile<WZ>::S &&
-           (unsigned)(lz - o.z) <= (unsigned)Tile<WZ>::SZ;
+    return (unsigned)(lx - o.x) <= (unsigned)T::SX && (unsigned)(ly - o.y) <= (unsigned)T::SY &&
+           (unsigned)(lz - o.z) <= (unsigned)T::SZ;
 }
 
 // Is every cell a member of this box can occupy deep inside the grid (cbet_relocate.h, kRelocateDeep <= c <=
 // n - 3) -- and therefore also more than two cells from every exit plane?  A held lane's low corner lies in
 // [o, o + S], its cell index c is the low corner or one less.  Scalar arithmetic only.
-template <int WZ>
+template <class T>
 __device__ __forceinline__ bool box_deep_inside(const Origin &o, int nx, int ny, int nz)
 {
-    using T = Tile<WZ>;
-    return o.x - 1 >= kRelocateDeep && o.x + T::S <= nx - 3 && o.y - 1 >= kRelocateDeep && o.y + T::S <= ny - 3 &&
+    return o.x - 1 >= kRelocateDeep && o.x + T::SX <= nx - 3 && o.y - 1 >= kRelocateDeep && o.y + T::SY <= ny - 3 &&
            o.z - 1 >= kRelocateDeep && o.z + T::SZ <= nz - 3;
 }
 
@@ -291,13 +292,14 @@ constexpr double kFarJump = 1.4998;   // relocate_deep_interior's validity bound
 template <int WZ, bool GENERIC, int CBET>
 __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(const TraceArgs a)
 {
-    using T = Tile<WZ>;            // box A
-    // Box B holds the few lanes that left A: four single z-planes in the dense layout, 2 KB.  Occupancy is what this
+    using T = Tile<8, 8, WZ, true>;   // box A
+    // Box B holds the few lanes that left A: 4 x 8 x 8 nodes in the dense layout, 2 KB.  Occupancy is what this
     // latency-bound loop responds to (256^3 pass: 25.7 ms at 8 waves per CU, 21.9 at 11, 20.9 at 12, 19.3 at 14), and
-    // the LDS is what caps it: 8 z-planes for B (4 KB, 12 waves) halve the window misses (0.5 % against 1.0 % of the
-    // ray-steps) but cost more than they save; A needs its padding (dense: 40 LDS cycles per ds_add_f64, 27 ms).
-    constexpr int WZB = 4;
-    using TB = Tile<WZB, false>;
+    // the LDS is what caps it: a 4 KB B (8 x 8 x 8, 12 waves) halves the window misses but costs more than it saves, and
+    // A needs its padding (dense: 40 LDS cycles per ds_add_f64, 27 ms; row pad only or plane pad only: +0.5 ms).  Shapes
+    // of the 2 KB, 256^3 pass: 8x8x4 19.26 ms (misses 1.00 % of ray-steps), 8x4x8 19.09 (0.87 %), 4x8x8 18.81 (0.86 %),
+    // 4x4x16 19.11 (1.04 %), 4x16x4 / 16x4x4 19.7 (1.18 %); placing a new B off-centre towards A changes nothing.
+    using TB = Tile<4, 8, 8, false>;
     constexpr bool IDX64 = GENERIC;
     constexpr int NC = (CBET == 4) ? 4 : 1;
     constexpr int NSLOT = T::N + TB::N;                   // box A, box B
@@ -338,8 +340,8 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
     {
         const int src = ((live >> 27) & 1ull) ? 27 : (__ffsll((long long)live) - 1);
         for (int z = lane; z < NLDS; z += kWave) s_val[z] = 0.0;
-        oA.x = __builtin_amdgcn_readlane(s.ci, src) + 1 - T::W / 2;
-        oA.y = __builtin_amdgcn_readlane(s.cj, src) + 1 - T::W / 2;
+        oA.x = __builtin_amdgcn_readlane(s.ci, src) + 1 - T::WX / 2;
+        oA.y = __builtin_amdgcn_readlane(s.cj, src) + 1 - T::WY / 2;
         oA.z = __builtin_amdgcn_readlane(s.ck, src) + 1 - 4;
         if (T::BRICK) oA.z &= ~7;
         __syncthreads();
@@ -523,50 +525,52 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
             // -- nothing has to move.  (The boxes follow on demand: the step in which a lane leaves is the step in
             // which its box is shifted, before anything is deposited.)
             const unsigned long long memA = live & ~hbm, memB = live & hbm;
-            unsigned long long out_core = memA & ~(CBET_BALLOT((unsigned)(lx - oA.x) <= (unsigned)T::S) &
-                                                   CBET_BALLOT((unsigned)(ly - oA.y) <= (unsigned)T::S) &
+            unsigned long long out_core = memA & ~(CBET_BALLOT((unsigned)(lx - oA.x) <= (unsigned)T::SX) &
+                                                   CBET_BALLOT((unsigned)(ly - oA.y) <= (unsigned)T::SY) &
                                                    CBET_BALLOT((unsigned)(lz - oA.z) <= (unsigned)T::SZ));
             if (b_active) {   // scalar branch
                 wc.slabs_bsteps += 1u;
-                out_core |= memB & ~(CBET_BALLOT((unsigned)(lx - oB.x) <= (unsigned)TB::S) &
-                                     CBET_BALLOT((unsigned)(ly - oB.y) <= (unsigned)TB::S) &
+                out_core |= memB & ~(CBET_BALLOT((unsigned)(lx - oB.x) <= (unsigned)TB::SX) &
+                                     CBET_BALLOT((unsigned)(ly - oB.y) <= (unsigned)TB::SY) &
                                      CBET_BALLOT((unsigned)(lz - oB.z) <= (unsigned)TB::SZ));
                 tile_off = homeB ? T::N : 0;
             }
             if (out_core != 0ull) {
                 // box A follows the lanes whose home it is
-                bool moved = follow_box<WZ, true, NC>(a, tileA, oA, memA, lx, ly, lz, lane, edep, sXh, sYh, wc, dfr, NSLOT, a.comp_stride);
+                bool moved = follow_box<T, true, NC>(a, tileA, oA, memA, lx, ly, lz, lane, edep, sXh, sYh, wc, dfr, NSLOT, a.comp_stride);
                 dfr_pending = dfr_pending || moved;
                 const unsigned long long lost_mask =
-                    memA & ~(CBET_BALLOT((unsigned)(lx - oA.x) <= (unsigned)T::S) & CBET_BALLOT((unsigned)(ly - oA.y) <= (unsigned)T::S) &
+                    memA & ~(CBET_BALLOT((unsigned)(lx - oA.x) <= (unsigned)T::SX) & CBET_BALLOT((unsigned)(ly - oA.y) <= (unsigned)T::SY) &
                              CBET_BALLOT((unsigned)(lz - oA.z) <= (unsigned)T::SZ));
                 if (lost_mask == 0ull && !b_active) {
                     // the usual outcome: A moved and holds every live lane again (inbox = alive, tile_off = 0 stand)
-                    deep = box_deep_inside<WZ>(oA, nx, ny, nz);
+                    deep = box_deep_inside<T>(oA, nx, ny, nz);
                 } else {
-                    const bool inA = alive && holds<WZ>(oA, lx, ly, lz);
+                    const bool inA = alive && holds<T>(oA, lx, ly, lz);
                     const bool lost = alive && !homeB && !inA;
                     // lanes that fell out of A look for a home in B, which follows its own lanes only (letting it chase the
                     // lost ones as well was measured: more misses, 0.63 % against 0.48 % of the ray-steps); an idle B is
                     // re-created around the first lost lane
                     if (b_active) {  // scalar branch
                         Deferred unused;
-                        follow_box<WZB, false, 1, false>(a, tileB, oB, memB, lx, ly, lz, lane, edep, sXh, sYh, wc, unused, 0, 0);
+                        follow_box<TB, false, 1>(a, tileB, oB, memB, lx, ly, lz, lane, edep, sXh, sYh, wc, unused, 0, 0);
                     } else if (lost_mask != 0ull) {
                         const int src = __ffsll((long long)lost_mask) - 1;
-                        oB.x = __builtin_amdgcn_readlane(lx, src) - (TB::W / 2 - 1);
-                        oB.y = __builtin_amdgcn_readlane(ly, src) - (TB::W / 2 - 1);
-                        oB.z = __builtin_amdgcn_readlane(lz, src) - TB::SZ / 2;
+                        const int sx = __builtin_amdgcn_readlane(lx, src), sy = __builtin_amdgcn_readlane(ly, src),
+                                  sz = __builtin_amdgcn_readlane(lz, src);
+                        oB.x = sx - (TB::WX / 2 - 1);
+                        oB.y = sy - (TB::WY / 2 - 1);
+                        oB.z = sz - TB::SZ / 2;
                         b_active = true;  // its tile is all zero: zeroed at start and flushed whenever it empties
                     }
-                    const bool inB = alive && holds<WZB>(oB, lx, ly, lz);
+                    const bool inB = alive && holds<TB>(oB, lx, ly, lz);
                     homeB = homeB || (lost && inB);
                     // a B lane that drifted out of B but back into A goes home
                     if (alive && homeB && !inB && inA) homeB = false;
                     hbm = CBET_BALLOT(alive && homeB);
                     if (hbm == 0ull) {
                         __builtin_amdgcn_wave_barrier();
-                        flush_box<WZB, 1, false>(a, tileB, oB, lane, edep, sXh, sYh, wc, 0, 0);
+                        flush_box<TB, 1>(a, tileB, oB, lane, edep, sXh, sYh, wc, 0, 0);
                         b_active = false;
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -575,10 +579,10 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
                     tile_off = useB ? T::N : 0;
                     const bool missed = CBET_BALLOT(alive && !inbox) != 0ull;
                     if (missed) wc.steps_miss += 1u;
-                    deep = !missed && box_deep_inside<WZ>(oA, nx, ny, nz) && (!b_active || box_deep_inside<WZB>(oB, nx, ny, nz));
+                    deep = !missed && box_deep_inside<T>(oA, nx, ny, nz) && (!b_active || box_deep_inside<TB>(oB, nx, ny, nz));
                 }
             } else if (!deep) {
-                deep = box_deep_inside<WZ>(oA, nx, ny, nz) && (!b_active || box_deep_inside<WZB>(oB, nx, ny, nz));
+                deep = box_deep_inside<T>(oA, nx, ny, nz) && (!b_active || box_deep_inside<TB>(oB, nx, ny, nz));
             }
         }
     
@@ -595,10 +599,10 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
 #pragma unroll
             for (int c = 0; c < 8; ++c) wgt[c] = wgt[c] * inc;   // a_c * increment
             if (inbox) {
-                // slot = (x & 7) * XS + (y & 7) * YS + (z & ZM) with the strides of the lane's tile
-                auto add8 = [&](int xs, int ys, int zm, int off) {
-                    const int x0 = (X0 & 7) * xs + off, x1 = (X1 & 7) * xs + off;
-                    const int y0 = (Y0 & 7) * ys, y1 = (Y1 & 7) * ys;
+                // slot = (x & XM) * XS + (y & YM) * YS + (z & ZM) with the masks and strides of the lane's tile
+                auto add8 = [&](int xm, int ym, int zm, int xs, int ys, int off) {
+                    const int x0 = (X0 & xm) * xs + off, x1 = (X1 & xm) * xs + off;
+                    const int y0 = (Y0 & ym) * ys, y1 = (Y1 & ym) * ys;
                     const int z0 = Z0 & zm, z1 = Z1 & zm;
                     const int s00 = x0 + y0, s10 = x1 + y0, s01 = x0 + y1, s11 = x1 + y1;
                     auto add = [&](int slot, double w) {
@@ -614,11 +618,12 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
                     add(s01 + z1, wgt[6]);
                     add(s11 + z1, wgt[7]);
                 };
-                if (!b_active) {   // scalar branch: everything goes to box A, compile-time strides
-                    add8(T::XS, T::YS, T::ZM, 0);
+                if (!b_active) {   // scalar branch: everything goes to box A, compile-time masks and strides
+                    add8(T::XM, T::YM, T::ZM, T::XS, T::YS, 0);
                 } else {
                     const bool toB = tile_off != 0;
-                    add8(toB ? TB::XS : T::XS, toB ? TB::YS : T::YS, toB ? TB::ZM : T::ZM, tile_off);
+                    add8(toB ? TB::XM : T::XM, toB ? TB::YM : T::YM, toB ? TB::ZM : T::ZM, toB ? TB::XS : T::XS,
+                         toB ? TB::YS : T::YS, tile_off);
                 }
             } else {
                 const int nX0 = __mul24(X0, sXh), nX1 = __mul24(X1, sXh), nY0 = __mul24(Y0, sYh), nY1 = __mul24(Y1, sYh);
@@ -638,7 +643,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
                 // box B / outside the boxes.
                 const int hi = s.ci + 1, hj = s.cj + 1, hk = s.ck + 1;
                 if (inbox && tile_off == 0) {
-                    const int own = T::slot_d(hi & 7, hj & 7, hk & T::ZM) + NSLOT;
+                    const int own = T::slot_d(hi & T::XM, hj & T::YM, hk & T::ZM) + NSLOT;
                     if (CBET_AUDIT(a, (unsigned)(own + 2 * T::DT) < (unsigned)NLDS)) {
                         __hip_atomic_fetch_add(&s_val[own], q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         __hip_atomic_fetch_add(&s_val[own + T::DT], q2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -679,8 +684,8 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
     }
     if (!T::BRICK && dfr.vz != 0.0) global_add(a, &edep[dfr.nz], dfr.vz);
     __syncthreads();
-    flush_box<WZ, NC>(a, tileA, oA, lane, edep, sXh, sYh, wc, NSLOT, a.comp_stride);
-    if (b_active) flush_box<WZB, 1, false>(a, tileB, oB, lane, edep, sXh, sYh, wc, 0, 0);
+    flush_box<T, NC>(a, tileA, oA, lane, edep, sXh, sYh, wc, NSLOT, a.comp_stride);
+    if (b_active) flush_box<TB, 1>(a, tileB, oB, lane, edep, sXh, sYh, wc, 0, 0);
 
     if (CBET && a.beam_gain) {  // one fp64 atomic per wave
         double t = gained;
