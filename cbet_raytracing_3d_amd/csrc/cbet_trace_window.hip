@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
     double *const edep = a.edep + (long)(beam - a.grid_beam0) * a.grid_stride;
     const bool absorb = GENERIC ? (a.absorption == 1) : true;   // def.cuh:118
 
-    Ray s;
+    Ray s = {};   // holes and culled rays keep zeros: their lanes run the arithmetic below on harmless values
     const int li = patch * kWave + lane;
     const int pre_raynum = li < a.nlive ? a.live[li] : -1;  // -1: hole in the 8x8 patch
     bool alive = pre_raynum >= 0;
@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
     const int sYh = nz + 2, sXh = (ny + 2) * (nz + 2);    // haloed edep strides (:5-7)
     unsigned cell = alive ? (unsigned)((s.ci * ny + s.cj) * nz + s.ck) : 0u;
     double fcx = (double)s.ci, fcy = (double)s.cj, fcz = (double)s.ck;   // the cell as the reference's (double)thisx
-    int nsteps = 0;
+    int tot_steps = 0;              // wave-uniform: ray-steps of this bundle (popcount of `live` per step)
     WaveCounters wc;
 
     double *const tileA = s_val, *const tileB = s_val + T::N;
@@ -374,12 +374,10 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
     const bool flx = (lane & 1) != 0, fly = (lane & 2) != 0, flz = (lane & 8) != 0;
     const int pfx = flx ? 1 : 0, pfy = fly ? 1 : 0, pfz = flz ? 1 : 0, nfx = 1 - pfx, nfy = 1 - pfy, nfz = 1 - pfz;
 
-    // Per-step values that cross the wave-uniform window logic between a step's two per-lane parts.  Declared
-    // outside the loop on purpose: written and read by live lanes only, a dead lane simply keeps its last value
-    // (re-declaring them per iteration makes the compiler spend ~20 moves per step on defaults for dead lanes).
-    int lx = 0, ly = 0, lz = 0;              // the lane's low corner (haloed)
-    int X0 = 0, X1 = 0, Y0 = 0, Y1 = 0, Z0 = 0, Z1 = 0;
-    double wgt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // The per-lane arithmetic of a step runs on ALL lanes, dead ones included (their state is garbage nobody reads):
+    // only memory accesses and the LDS / HBM adds are predicated.  Guarding the arithmetic with `if (alive)` costs
+    // exec-mask bookkeeping plus, for every value that crosses the window logic, a merge of "this step's" and "the
+    // dead lane's last" copy -- ~10 moves per step.
     double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;   // CBET = 4: the four field quantities a step deposits
 
     bool slow = true;                        // wave-uniform: this step runs the general (face-aware) forms
@@ -388,8 +386,8 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
     for (int tt = 0; tt < a.nt; ++tt) {                        // :207
         if (live == 0ull) break;
         wc.steps_miss += 1u << 16;
-        // ---- move (all lanes: a dead lane's state is never read again, so nothing here needs a lane mask and
-        // the wave-uniform decision below is taken outside every divergent region) ------------------------
+        tot_steps += __popcll(live);
+        // ---- move ------------------------------------------------------------------------------------------
         // :268-273 kick then drift (stencil values gathered during the previous step)
         s.vx -= st_kx;
         s.vy -= st_ky;
@@ -410,103 +408,103 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         // wave-uniform: this step runs the general (face-aware) forms
         slow = !deep || ((CBET_BALLOT(!(fabs(g0x) < kFarJump)) | CBET_BALLOT(!(fabs(g0y) < kFarJump)) |
                                      CBET_BALLOT(!(fabs(g0z) < kFarJump))) & live) != 0ull;
-        if (alive) {
-            // ---- relocate, gather -------------------------------------------------------------------
-            if (slow) {                        // near a face (or a far jump): closed form with the candidate bounds
-                s.ci = relocate_closed(s.ci, fx, nx);
-                s.cj = relocate_closed(s.cj, fy, ny);
-                s.ck = relocate_closed(s.ck, fz, nz);
-            } else {
-                s.ci = qi;
-                s.cj = qj;
-                s.ck = qk;
+        // ---- relocate, gather -------------------------------------------------------------------
+        if (slow) {                        // near a face (or a far jump): closed form with the candidate bounds
+            s.ci = relocate_closed(s.ci, fx, nx);
+            s.cj = relocate_closed(s.cj, fy, ny);
+            s.ck = relocate_closed(s.ck, fz, nz);
+        } else {
+            s.ci = qi;
+            s.cj = qj;
+            s.ck = qk;
+        }
+        fcx = (double)s.ci;
+        fcy = (double)s.cj;
+        fcz = (double)s.ck;
+        cell = (unsigned)(__mul24(__mul24(s.ci, ny) + s.cj, nz) + s.ck);
+        // :296-298 absorption coefficient at the new node and the NEXT step's kicks
+        if (alive) gather_record();
+        // ---- weights (:319-339) -----------------------------------------------------------------
+        // Each weight is (Fz * Fy) * Fx * inc with F = (1-d) for the ray's own node along that axis and F = d
+        // for the neighbour on the `sign` side (:329-336).  The neighbour lies on the side of the offset's sign
+        // (:338-339), so a lane's two nodes per axis are {low, low + 1}, low = own - 1 iff the offset is negative.
+        // Corner order: the eight (node, weight) pairs are the same whatever order they are enumerated in, and
+        // every product keeps the reference's operand order.  Three lane bits swap which of an axis's two nodes
+        // is visited first, so rays a quarter cell apart that share all 8 target nodes hit different nodes in any
+        // one ds_add_f64 instead of serialising on one address: a patch row is lanes 8r..8r+7 and with 4 rays
+        // per zone the 16 lanes of rows 0-3 x columns 0-3 share a cell; bits 0 and 1 (column) and bit 3 (row)
+        // give those 16 lanes all 8 orders, two lanes each.
+        const double ox = (fx - fcx) - 0.5, oy = (fy - fcy) - 0.5, oz = (fz - fcz) - 0.5;   // :319-321
+        const double dm = 1.0 - fabs(ox), dn = 1.0 - fabs(oy), dl = 1.0 - fabs(oz);
+        const double ax_own = 1.0 - dm, ay_own = 1.0 - dn, az_own = 1.0 - dl;
+        const double Fx0 = flx ? dm : ax_own, Fx1 = flx ? ax_own : dm;
+        const double Fy0 = fly ? dn : ay_own, Fy1 = fly ? ay_own : dn;
+        const double Fz0 = flz ? dl : az_own, Fz1 = flz ? az_own : dl;
+        // Node indices.  The offsets are xtemp - thisx - 0.5 with |xtemp - thisx| < 0.5001, i.e. negative except in
+        // a 1e-4-wide sliver: when they are negative on every axis of every live lane (a ballot of the three sign
+        // compares: ~98 % of the wave-steps) the low corner is the own node minus one and the first-visited node
+        // depends on the lane's flip bits only.
+        int lx, ly, lz;                       // the lane's low corner (haloed)
+        int X0, X1, Y0, Y1, Z0, Z1;
+        if (((CBET_BALLOT(!(ox < 0)) | CBET_BALLOT(!(oy < 0)) | CBET_BALLOT(!(oz < 0))) & live) == 0ull) {   // scalar branch
+            lx = s.ci;
+            ly = s.cj;
+            lz = s.ck;
+            X0 = s.ci + nfx; X1 = s.ci + pfx;
+            Y0 = s.cj + nfy; Y1 = s.cj + pfy;
+            Z0 = s.ck + nfz; Z1 = s.ck + pfz;
+        } else {
+            const bool ngx = ox < 0, ngy = oy < 0, ngz = oz < 0;
+            lx = s.ci + 1 - (ngx ? 1 : 0);
+            ly = s.cj + 1 - (ngy ? 1 : 0);
+            lz = s.ck + 1 - (ngz ? 1 : 0);
+            // first-visited node: the own node (the high one iff the offset is negative) unless flipped
+            const bool hx = ngx != flx, hy = ngy != fly, hz = ngz != flz;
+            X0 = lx + (hx ? 1 : 0); X1 = lx + (hx ? 0 : 1);
+            Y0 = ly + (hy ? 1 : 0); Y1 = ly + (hy ? 0 : 1);
+            Z0 = lz + (hz ? 1 : 0); Z1 = lz + (hz ? 0 : 1);
+        }
+        const double zy00 = Fz0 * Fy0, zy10 = Fz1 * Fy0, zy01 = Fz0 * Fy1, zy11 = Fz1 * Fy1;
+        // order (x,y,z) = (0,0,0) (1,0,0) (0,0,1) (1,0,1) (0,1,0) (1,1,0) (0,1,1) (1,1,1) -- :341-348 without the flips
+        double wgt[8];
+        wgt[0] = zy00 * Fx0;
+        wgt[1] = zy00 * Fx1;
+        wgt[2] = zy10 * Fx0;
+        wgt[3] = zy10 * Fx1;
+        wgt[4] = zy01 * Fx0;
+        wgt[5] = zy01 * Fx1;
+        wgt[6] = zy11 * Fx0;
+        wgt[7] = zy11 * Fx1;
+        if (CBET && alive) {   // the gain gathers are memory accesses: live lanes only
+            // path length of the step; u_eff = the ray's energy averaged over the step
+            double ds = 0.0;
+            if (gk || CBET == 4) ds = sqrt(s.vx * s.vx + s.vy * s.vy + s.vz * s.vz) * a.dt;
+            double u_eff = s.uray;
+            if (gk) {
+                // K at the eight deposit nodes, weighted like the deposit.  The pairwise tree makes the
+                // sum independent of the corner order (the flips swap operands of commutative adds only).
+                const int nX0 = __mul24(X0, sXh), nX1 = __mul24(X1, sXh), nY0 = __mul24(Y0, sYh), nY1 = __mul24(Y1, sYh);
+                const double g0 = gain_load<IDX64>(a, gk, (unsigned)(nX0 + nY0 + Z0)), g1 = gain_load<IDX64>(a, gk, (unsigned)(nX1 + nY0 + Z0));
+                const double g2 = gain_load<IDX64>(a, gk, (unsigned)(nX0 + nY0 + Z1)), g3 = gain_load<IDX64>(a, gk, (unsigned)(nX1 + nY0 + Z1));
+                const double g4 = gain_load<IDX64>(a, gk, (unsigned)(nX0 + nY1 + Z0)), g5 = gain_load<IDX64>(a, gk, (unsigned)(nX1 + nY1 + Z0));
+                const double g6 = gain_load<IDX64>(a, gk, (unsigned)(nX0 + nY1 + Z1)), g7 = gain_load<IDX64>(a, gk, (unsigned)(nX1 + nY1 + Z1));
+                const double k01 = wgt[0] * g0 + wgt[1] * g1, k23 = wgt[2] * g2 + wgt[3] * g3;
+                const double k45 = wgt[4] * g4 + wgt[5] * g5, k67 = wgt[6] * g6 + wgt[7] * g7;
+                double x = ((k01 + k23) + (k45 + k67)) * ds;
+                if (x > a.max_exponent) x = a.max_exponent;
+                if (x < -a.max_exponent) x = -a.max_exponent;
+                const double phi = phi_det(x);
+                const double dg = s.uray * (x * phi);
+                u_eff = s.uray * phi;
+                gained += dg;
+                s.uray = s.uray + dg;
             }
-            fcx = (double)s.ci;
-            fcy = (double)s.cj;
-            fcz = (double)s.ck;
-            cell = (unsigned)(__mul24(__mul24(s.ci, ny) + s.cj, nz) + s.ck);
-            // :296-298 absorption coefficient at the new node and the NEXT step's kicks
-            gather_record();
-            // ---- weights (:319-339) -----------------------------------------------------------------
-            // Each weight is (Fz * Fy) * Fx * inc with F = (1-d) for the ray's own node along that axis and F = d
-            // for the neighbour on the `sign` side (:329-336).  The neighbour lies on the side of the offset's sign
-            // (:338-339), so a lane's two nodes per axis are {low, low + 1}, low = own - 1 iff the offset is negative.
-            // Corner order: the eight (node, weight) pairs are the same whatever order they are enumerated in, and
-            // every product keeps the reference's operand order.  Three lane bits swap which of an axis's two nodes
-            // is visited first, so rays a quarter cell apart that share all 8 target nodes hit different nodes in any
-            // one ds_add_f64 instead of serialising on one address: a patch row is lanes 8r..8r+7 and with 4 rays
-            // per zone the 16 lanes of rows 0-3 x columns 0-3 share a cell; bits 0 and 1 (column) and bit 3 (row)
-            // give those 16 lanes all 8 orders, two lanes each.
-            const double ox = (fx - fcx) - 0.5, oy = (fy - fcy) - 0.5, oz = (fz - fcz) - 0.5;   // :319-321
-            const double dm = 1.0 - fabs(ox), dn = 1.0 - fabs(oy), dl = 1.0 - fabs(oz);
-            const double ax_own = 1.0 - dm, ay_own = 1.0 - dn, az_own = 1.0 - dl;
-            const double Fx0 = flx ? dm : ax_own, Fx1 = flx ? ax_own : dm;
-            const double Fy0 = fly ? dn : ay_own, Fy1 = fly ? ay_own : dn;
-            const double Fz0 = flz ? dl : az_own, Fz1 = flz ? az_own : dl;
-            // Node indices.  The offsets are xtemp - thisx - 0.5 with |xtemp - thisx| < 0.5001, i.e. negative except in
-            // a 1e-4-wide sliver: when they are negative on every axis of every live lane (a ballot of the three sign
-            // compares: ~98 % of the wave-steps) the low corner is the own node minus one and the first-visited node
-            // depends on the lane's flip bits only.
-            if ((CBET_BALLOT(!(ox < 0)) | CBET_BALLOT(!(oy < 0)) | CBET_BALLOT(!(oz < 0))) == 0ull) {   // scalar branch
-                lx = s.ci;
-                ly = s.cj;
-                lz = s.ck;
-                X0 = s.ci + nfx; X1 = s.ci + pfx;
-                Y0 = s.cj + nfy; Y1 = s.cj + pfy;
-                Z0 = s.ck + nfz; Z1 = s.ck + pfz;
-            } else {
-                const bool ngx = ox < 0, ngy = oy < 0, ngz = oz < 0;
-                lx = s.ci + 1 - (ngx ? 1 : 0);
-                ly = s.cj + 1 - (ngy ? 1 : 0);
-                lz = s.ck + 1 - (ngz ? 1 : 0);
-                // first-visited node: the own node (the high one iff the offset is negative) unless flipped
-                const bool hx = ngx != flx, hy = ngy != fly, hz = ngz != flz;
-                X0 = lx + (hx ? 1 : 0); X1 = lx + (hx ? 0 : 1);
-                Y0 = ly + (hy ? 1 : 0); Y1 = ly + (hy ? 0 : 1);
-                Z0 = lz + (hz ? 1 : 0); Z1 = lz + (hz ? 0 : 1);
+            if (CBET == 4) {
+                q0 = u_eff * ds;
+                q1 = u_eff * (s.vx * a.dt);
+                q2 = u_eff * (s.vy * a.dt);
+                q3 = u_eff * (s.vz * a.dt);
             }
-            const double zy00 = Fz0 * Fy0, zy10 = Fz1 * Fy0, zy01 = Fz0 * Fy1, zy11 = Fz1 * Fy1;
-            // order (x,y,z) = (0,0,0) (1,0,0) (0,0,1) (1,0,1) (0,1,0) (1,1,0) (0,1,1) (1,1,1) -- :341-348 without the flips
-            wgt[0] = zy00 * Fx0;
-            wgt[1] = zy00 * Fx1;
-            wgt[2] = zy10 * Fx0;
-            wgt[3] = zy10 * Fx1;
-            wgt[4] = zy01 * Fx0;
-            wgt[5] = zy01 * Fx1;
-            wgt[6] = zy11 * Fx0;
-            wgt[7] = zy11 * Fx1;
-            if (CBET) {
-                // path length of the step; u_eff = the ray's energy averaged over the step
-                double ds = 0.0;
-                if (gk || CBET == 4) ds = sqrt(s.vx * s.vx + s.vy * s.vy + s.vz * s.vz) * a.dt;
-                double u_eff = s.uray;
-                if (gk) {
-                    // K at the eight deposit nodes, weighted like the deposit.  The pairwise tree makes the
-                    // sum independent of the corner order (the flips swap operands of commutative adds only).
-                    const int nX0 = __mul24(X0, sXh), nX1 = __mul24(X1, sXh), nY0 = __mul24(Y0, sYh), nY1 = __mul24(Y1, sYh);
-                    const double g0 = gain_load<IDX64>(a, gk, (unsigned)(nX0 + nY0 + Z0)), g1 = gain_load<IDX64>(a, gk, (unsigned)(nX1 + nY0 + Z0));
-                    const double g2 = gain_load<IDX64>(a, gk, (unsigned)(nX0 + nY0 + Z1)), g3 = gain_load<IDX64>(a, gk, (unsigned)(nX1 + nY0 + Z1));
-                    const double g4 = gain_load<IDX64>(a, gk, (unsigned)(nX0 + nY1 + Z0)), g5 = gain_load<IDX64>(a, gk, (unsigned)(nX1 + nY1 + Z0));
-                    const double g6 = gain_load<IDX64>(a, gk, (unsigned)(nX0 + nY1 + Z1)), g7 = gain_load<IDX64>(a, gk, (unsigned)(nX1 + nY1 + Z1));
-                    const double k01 = wgt[0] * g0 + wgt[1] * g1, k23 = wgt[2] * g2 + wgt[3] * g3;
-                    const double k45 = wgt[4] * g4 + wgt[5] * g5, k67 = wgt[6] * g6 + wgt[7] * g7;
-                    double x = ((k01 + k23) + (k45 + k67)) * ds;
-                    if (x > a.max_exponent) x = a.max_exponent;
-                    if (x < -a.max_exponent) x = -a.max_exponent;
-                    const double phi = phi_det(x);
-                    const double dg = s.uray * (x * phi);
-                    u_eff = s.uray * phi;
-                    gained += dg;
-                    s.uray = s.uray + dg;
-                }
-                if (CBET == 4) {
-                    q0 = u_eff * ds;
-                    q1 = u_eff * (s.vx * a.dt);
-                    q2 = u_eff * (s.vy * a.dt);
-                    q3 = u_eff * (s.vz * a.dt);
-                }
-            }
-            ++nsteps;
         }
         if (dfr_pending) {                     // scalar branch: last step's retired planes go to HBM now, behind this step's gathers
             dfr_pending = false;
@@ -587,7 +585,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         }
     
         // ---- deposit (:305-311, :341-348) -------------------------------------------------------------
-        if (alive) {
+        {
             double inc;
             if (absorb) {
                 inc = kap * s.uray;
@@ -625,7 +623,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
                     add8(toB ? TB::XM : T::XM, toB ? TB::YM : T::YM, toB ? TB::ZM : T::ZM, toB ? TB::XS : T::XS,
                          toB ? TB::YS : T::YS, tile_off);
                 }
-            } else {
+            } else if (alive) {
                 const int nX0 = __mul24(X0, sXh), nX1 = __mul24(X1, sXh), nY0 = __mul24(Y0, sYh), nY1 = __mul24(Y1, sYh);
                 global_add(a, &edep[nX0 + nY0 + Z0], wgt[0]);
                 global_add(a, &edep[nX1 + nY0 + Z0], wgt[1]);
@@ -638,7 +636,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
                 wc.n_atomics += 8;
                 ++wc.n_miss;
             }
-            if (CBET == 4) {
+            if (CBET == 4 && alive) {
                 // Displacement components: the ray's own node only -- box A's tiles, or HBM for a lane of
                 // box B / outside the boxes.
                 const int hi = s.ci + 1, hj = s.cj + 1, hk = s.ck + 1;
@@ -694,7 +692,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         if (lane == 0 && t != 0.0) atomicAdd(&a.beam_gain[beam], t);
     }
     // counters: one atomic per wave and counter
-    const int tot_steps = wave_sum(nsteps), tot_rays = wave_sum(launched), tot_at = wave_sum(wc.n_atomics),
+    const int tot_rays = wave_sum(launched), tot_at = wave_sum(wc.n_atomics),
               tot_miss = wave_sum(wc.n_miss);
     if (lane == 0) {
         atomicAdd(&a.counters[kCntSteps], (unsigned long long)tot_steps);
