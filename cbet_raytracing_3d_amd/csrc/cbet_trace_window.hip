@@ -34,6 +34,8 @@
 namespace cbet {
 namespace {
 
+#define CBET_BALLOT(cond) __builtin_amdgcn_ballot_w64(cond)
+
 // A wave-private tile of fp64 accumulators covering WX x WY x WZ nodes (powers of two), addressed toroidally.
 template <int WX_, int WY_, int WZ_, bool PAD>
 struct Tile {
@@ -69,27 +71,25 @@ struct WaveCounters {
     int n_miss = 0;           // per lane: ray-steps deposited straight to HBM
     unsigned steps_miss = 0;  // wave-uniform, packed: wave-steps << 16 | wave-steps with a window miss
     unsigned slabs_bsteps = 0;// wave-uniform, packed: planes / bricks retired << 16 | wave-steps with box B live
+    int pend = 0;             // wave-uniform: vector-memory instructions issued since the step's record gather
 };
 
-// Take the plane `coord` (absolute, inside the box) of axis AX (0: x, 1: y) out of a tile: read the sums, zero
-// the non-zero ones and either hand them back in (dv, dn) -- value and flat haloed node -- so that the caller
-// can issue the global atomic LATER, behind the next step's gathers (loads, stores and atomics share one
-// in-order vmcnt on CDNA: an atomic issued before a load delays that load's data by the atomic's round trip),
-// or (DEFER = false) add them to HBM now.  A plane is W x WZ entries (W = the other lateral extent), z fastest
-// across lanes, so one wave instruction covers whole rows -- 64-B lines when the z origin is brick-aligned.
-template <class T, int AX, bool DEFER, int NC>
+// Take the plane `coord` (absolute, inside the box) of axis AX (0: x, 1: y) out of a tile: read the sums, zero the
+// non-zero ones and add them to HBM.  A plane is W x WZ entries (W = the other lateral extent), z fastest across
+// lanes, so one wave instruction covers whole rows -- 64-B lines when the z origin is brick-aligned.  Every vector
+// memory instruction that is really issued (some lane has a non-zero sum) is counted in wc.pend: the step's wait
+// for its record gather skips exactly that many younger instructions (see the kernel).
+template <class T, int AX, int NC>
 __device__ __forceinline__ void retire_plane(const TraceArgs &a, double *tile, const Origin &o, int coord, int lane,
-                                             double *edep, int sXh, int sYh, WaveCounters &wc, double (&dv)[2],
-                                             int (&dn)[2], int coff, long gstride)
+                                             double *edep, int sXh, int sYh, WaveCounters &wc, int coff, long gstride)
 {
     constexpr int WO = AX == 0 ? T::WY : T::WX;      // extent of the other lateral axis
     constexpr int IT = (WO * T::WZ + kWave - 1) / kWave;
-    static_assert(IT <= 2, "a plane is at most two entries per lane");
     const int fixed = coord & (AX == 0 ? T::XM : T::YM);
 #pragma unroll
     for (int e = 0; e < IT; ++e) {
         const int idx = e * kWave + lane;
-        if (WO * T::WZ < kWave && idx >= WO * T::WZ) continue;
+        const bool in_plane = !(WO * T::WZ < kWave) || idx < WO * T::WZ;
         const int r0 = idx / T::WZ, r1 = idx & T::ZM;
         int slot, node, slot_d;
         const int k = abs_in<T::ZM>(o.z, r1);
@@ -102,12 +102,13 @@ __device__ __forceinline__ void retire_plane(const TraceArgs &a, double *tile, c
             slot_d = T::slot_d(r0, fixed, r1);
             node = abs_in<T::XM>(o.x, r0) * sXh + coord * sYh + k;
         }
-        if (!CBET_AUDIT(a, (unsigned)slot < (unsigned)T::N)) continue;
-        const double v = tile[slot];
+        const bool ok = in_plane && CBET_AUDIT(a, (unsigned)slot < (unsigned)T::N);
+        const double v = ok ? tile[slot] : 0.0;
         if (NC > 1) {
 #pragma unroll
             for (int q = 1; q < NC; ++q) {
-                const double vq = tile[coff + (q - 1) * T::DT + slot_d];
+                const double vq = ok ? tile[coff + (q - 1) * T::DT + slot_d] : 0.0;
+                wc.pend += (CBET_BALLOT(vq != 0.0) != 0ull) ? 1 : 0;
                 if (vq != 0.0) {
                     global_add(a, &edep[q * gstride + node], vq);
                     tile[coff + (q - 1) * T::DT + slot_d] = 0.0;
@@ -115,38 +116,33 @@ __device__ __forceinline__ void retire_plane(const TraceArgs &a, double *tile, c
                 }
             }
         }
+        wc.pend += (CBET_BALLOT(v != 0.0) != 0ull) ? 1 : 0;
         if (v != 0.0) {  // only nodes that received deposits are non-zero, hence valid
             tile[slot] = 0.0;
             ++wc.n_atomics;
-            if (DEFER) {
-                dv[e] = v;
-                dn[e] = node;
-            } else {
-                global_add(a, &edep[node], v);
-            }
+            global_add(a, &edep[node], v);
         }
     }
 }
 
 // z, single planes (tiles without bricks): the plane is WX x WY (x, y) entries, at most one per lane, each in its
 // own 64-B line of HBM.
-template <class T, bool DEFER, int NC>
+template <class T, int NC>
 __device__ __forceinline__ void retire_zplane(const TraceArgs &a, double *tile, const Origin &o, int coord, int lane,
-                                              double *edep, int sXh, int sYh, WaveCounters &wc, double &dv, int &dn,
-                                              int coff, long gstride)
+                                              double *edep, int sXh, int sYh, WaveCounters &wc, int coff, long gstride)
 {
     static_assert(T::WX * T::WY <= kWave, "one z-plane entry per lane");
-    if (T::WX * T::WY < kWave && lane >= T::WX * T::WY) return;
     const int r0 = lane / T::WY, r1 = lane & T::YM, fixed = coord & T::ZM;
     const int slot = r0 * T::XS + r1 * T::YS + fixed;
     const int node = abs_in<T::XM>(o.x, r0) * sXh + abs_in<T::YM>(o.y, r1) * sYh + coord;
-    if (!CBET_AUDIT(a, (unsigned)slot < (unsigned)T::N)) return;
-    const double v = tile[slot];
+    const bool ok = (!(T::WX * T::WY < kWave) || lane < T::WX * T::WY) && CBET_AUDIT(a, (unsigned)slot < (unsigned)T::N);
+    const double v = ok ? tile[slot] : 0.0;
     if (NC > 1) {
         const int slot_d = T::slot_d(r0, r1, fixed);
 #pragma unroll
         for (int q = 1; q < NC; ++q) {
-            const double vq = tile[coff + (q - 1) * T::DT + slot_d];
+            const double vq = ok ? tile[coff + (q - 1) * T::DT + slot_d] : 0.0;
+            wc.pend += (CBET_BALLOT(vq != 0.0) != 0ull) ? 1 : 0;
             if (vq != 0.0) {
                 global_add(a, &edep[q * gstride + node], vq);
                 tile[coff + (q - 1) * T::DT + slot_d] = 0.0;
@@ -154,15 +150,11 @@ __device__ __forceinline__ void retire_zplane(const TraceArgs &a, double *tile, 
             }
         }
     }
+    wc.pend += (CBET_BALLOT(v != 0.0) != 0ull) ? 1 : 0;
     if (v != 0.0) {
         tile[slot] = 0.0;
         ++wc.n_atomics;
-        if (DEFER) {
-            dv = v;
-            dn = node;
-        } else {
-            global_add(a, &edep[node], v);
-        }
+        global_add(a, &edep[node], v);
     }
 }
 
@@ -181,6 +173,7 @@ __device__ __forceinline__ void retire_zbrick(const TraceArgs &a, double *tile, 
         const int slot = tx * T::XS + base_slot;
         if (!CBET_AUDIT(a, (unsigned)slot < (unsigned)T::N)) continue;
         const double v = tile[slot];
+        wc.pend += (CBET_BALLOT(v != 0.0) != 0ull) ? 1 : 0;
         if (v != 0.0) {
             tile[slot] = 0.0;
             ++wc.n_atomics;
@@ -194,18 +187,9 @@ template <class T, int NC>
 __device__ __forceinline__ void flush_box(const TraceArgs &a, double *tile, const Origin &o, int lane, double *edep,
                                           int sXh, int sYh, WaveCounters &wc, int coff, long gstride)
 {
-    double dv[2];
-    int dn[2];
     for (int t = 0; t < T::WX; ++t)
-        retire_plane<T, 0, false, NC>(a, tile, o, o.x + t, lane, edep, sXh, sYh, wc, dv, dn, coff, gstride);
+        retire_plane<T, 0, NC>(a, tile, o, o.x + t, lane, edep, sXh, sYh, wc, coff, gstride);
 }
-
-// Deferred plane sums of box A: x and y planes (at most two entries per lane each) and, for tiles without bricks,
-// one z-plane entry.
-struct Deferred {
-    double vx[2] = {0.0, 0.0}, vy[2] = {0.0, 0.0}, vz = 0.0;
-    int nx[2] = {0, 0}, ny[2] = {0, 0}, nz = 0;
-};
 
 // Wave-uniform decision of the hysteresis rule for one axis followed by single planes: -1 / +1 = shift the
 // origin down / up, 0 = stay.  r = the lane's low-corner offset from the origin, mm = ballot of the box's member
@@ -236,18 +220,18 @@ __device__ __forceinline__ int follow_brick_axis(int r, unsigned long long mm)
 // that count for this box.  The decisions are taken first, as scalars; the planes that leave are then written
 // back and the origin is moved by plain scalar arithmetic outside every divergent region (so that it stays in
 // scalar registers).  Returns true when the origin moved.
-template <class T, bool DEFER, int NC>
+template <class T, int NC>
 __device__ __forceinline__ bool follow_box(const TraceArgs &a, double *tile, Origin &o, unsigned long long mm, int lx,
                                            int ly, int lz, int lane, double *edep, int sXh, int sYh, WaveCounters &wc,
-                                           Deferred &d, int coff, long gstride)
+                                           int coff, long gstride)
 {
     const int dx = follow_plane_axis(lx - o.x, mm, T::SX);
     if (dx != 0)
-        retire_plane<T, 0, DEFER, NC>(a, tile, o, dx < 0 ? o.x + T::WX - 1 : o.x, lane, edep, sXh, sYh, wc, d.vx, d.nx, coff, gstride);
+        retire_plane<T, 0, NC>(a, tile, o, dx < 0 ? o.x + T::WX - 1 : o.x, lane, edep, sXh, sYh, wc, coff, gstride);
     o.x += dx;
     const int dy = follow_plane_axis(ly - o.y, mm, T::SY);
     if (dy != 0)
-        retire_plane<T, 1, DEFER, NC>(a, tile, o, dy < 0 ? o.y + T::WY - 1 : o.y, lane, edep, sXh, sYh, wc, d.vy, d.ny, coff, gstride);
+        retire_plane<T, 1, NC>(a, tile, o, dy < 0 ? o.y + T::WY - 1 : o.y, lane, edep, sXh, sYh, wc, coff, gstride);
     o.y += dy;
     int dz;
     if constexpr (T::BRICK) {
@@ -256,7 +240,7 @@ __device__ __forceinline__ bool follow_box(const TraceArgs &a, double *tile, Ori
     } else {
         dz = follow_plane_axis(lz - o.z, mm, T::SZ);
         if (dz != 0)
-            retire_zplane<T, DEFER, NC>(a, tile, o, dz < 0 ? o.z + T::WZ - 1 : o.z, lane, edep, sXh, sYh, wc, d.vz, d.nz, coff, gstride);
+            retire_zplane<T, NC>(a, tile, o, dz < 0 ? o.z + T::WZ - 1 : o.z, lane, edep, sXh, sYh, wc, coff, gstride);
     }
     o.z += dz;
     const bool moved = (dx | dy | dz) != 0;
@@ -282,10 +266,65 @@ __device__ __forceinline__ bool box_deep_inside(const Origin &o, int nx, int ny,
 }
 
 // ---------------------------------------------------------------------------------------------
+// The record gather and its wait, hand-scheduled.  Loads, stores and atomics share ONE in-order counter (vmcnt) on
+// CDNA: a wait for a load also waits for every vector-memory instruction issued before it, and the compiler, which
+// cannot count the conditionally issued write-back atomics of a step, waits with vmcnt(0) -- i.e. for the atomics
+// issued AFTER the gather as well, a full round trip to the memory-side atomic unit in every step that moved a box.
+// So the gather is issued from inline assembly (the compiler inserts no wait for it), the write-back paths count
+// the vector-memory instructions they really issue (WaveCounters::pend, wave-uniform), and the step waits with the
+// largest vmcnt(N), N <= pend, of a small ladder: the gather has arrived, the younger atomics stay in flight and have
+// until the next step's wait -- a whole step -- to complete.
+// ---------------------------------------------------------------------------------------------
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void record_issue(const StepRecord *base, unsigned cell, dbl2 &kxy, dbl2 &kzk)
+{
+    const char *p = reinterpret_cast<const char *>(base) + ((unsigned long long)cell << 5);
+    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
+                 : "=&v"(kxy), "=&v"(kzk)
+                 : "v"(p)
+                 : "memory");
+}
+
+// pend = vector-memory instructions issued since record_issue (exact, or an underestimate -- never more)
+__device__ __forceinline__ void record_wait(dbl2 &kxy, dbl2 &kzk, int pend)
+{
+    asm volatile("s_cmp_eq_u32 %2, 0\n\t"
+                 "s_cbranch_scc0 .Lrw_nz_%=\n\t"
+                 "s_waitcnt vmcnt(0)\n\t"
+                 "s_branch .Lrw_end_%=\n"
+                 ".Lrw_nz_%=:\n\t"
+                 "s_cmp_ge_u32 %2, 8\n\t"
+                 "s_cbranch_scc1 .Lrw_8_%=\n\t"
+                 "s_cmp_ge_u32 %2, 4\n\t"
+                 "s_cbranch_scc1 .Lrw_4_%=\n\t"
+                 "s_cmp_ge_u32 %2, 2\n\t"
+                 "s_cbranch_scc1 .Lrw_2_%=\n\t"
+                 "s_waitcnt vmcnt(1)\n\t"
+                 "s_branch .Lrw_end_%=\n"
+                 ".Lrw_2_%=:\n\t"
+                 "s_waitcnt vmcnt(2)\n\t"
+                 "s_branch .Lrw_end_%=\n"
+                 ".Lrw_4_%=:\n\t"
+                 "s_waitcnt vmcnt(4)\n\t"
+                 "s_branch .Lrw_end_%=\n"
+                 ".Lrw_8_%=:\n\t"
+                 "s_waitcnt vmcnt(8)\n"
+                 ".Lrw_end_%=:"
+                 : "+v"(kxy), "+v"(kzk)
+                 : "s"(pend)
+                 : "memory", "scc");
+}
+
+// ---------------------------------------------------------------------------------------------
 // The kernel.
 // ---------------------------------------------------------------------------------------------
-#define CBET_BALLOT(cond) __builtin_amdgcn_ballot_w64(cond)
 
+#ifdef CBET_DEBUG_BOUNDS
+constexpr bool kAudited = true;
+#else
+constexpr bool kAudited = false;
+#endif
 constexpr double kNearTol = 0.5001;   // launch_ray_XZ.cu:132, the nearest-node tolerance
 constexpr double kFarJump = 1.4998;   // relocate_deep_interior's validity bound on |f - cell|
 
@@ -353,22 +392,21 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
     // at the ray's node) is gathered as soon as the new node is known; the absorption coefficient is used by the
     // same step's deposit, the kicks by the NEXT step's move -- so the gather is in flight during the whole
     // deposit phase.  One aligned 32-byte gather per lane and step.
-    double st_kx = 0, st_ky = 0, st_kz = 0, kap = 0;
-    auto gather_record = [&]() {
+    dbl2 rec_kxy, rec_kzk;                   // {kx, ky}, {kz, kappa} of the ray's node
+    auto gather_record = [&]() {             // all lanes (a dead lane reads node 0); see record_issue
+        unsigned c = alive ? cell : 0u;
 #ifdef CBET_DEBUG_BOUNDS
-        if (!(cell < a.audit_nodes)) { audit_fail(a); return; }
+        if (!(c < a.audit_nodes)) { audit_fail(a); c = 0u; }
 #endif
-        const double4 r = reinterpret_cast<const double4 *>(a.steprec)[cell];
-        st_kx = r.x;
-        st_ky = r.y;
-        st_kz = r.z;
-        kap = r.w;
+        record_issue(a.steprec, c, rec_kxy, rec_kzk);
+        wc.pend = 0;
     };
-    if (alive) gather_record();
+    // CBET hooks and audited builds issue vector loads the compiler tracks itself: wait for everything there
+    auto await_record = [&]() { record_wait(rec_kxy, rec_kzk, (CBET != 0 || kAudited) ? 0 : __builtin_amdgcn_readfirstlane(wc.pend)); };
+    gather_record();
+    await_record();
     const double *const gk = CBET && a.gain ? a.gain + (long)(beam - a.grid_beam0) * a.hsize : nullptr;  // this beam's gain grid
     double gained = 0.0;                     // CBET: energy this lane's ray gained
-    Deferred dfr;
-    bool dfr_pending = false;                // wave-uniform: box A retired a plane in the previous step
 
     // lane-dependent corner order (see the weights): which of an axis's two nodes a lane visits first
     const bool flx = (lane & 1) != 0, fly = (lane & 2) != 0, flz = (lane & 8) != 0;
@@ -389,9 +427,9 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         tot_steps += __popcll(live);
         // ---- move ------------------------------------------------------------------------------------------
         // :268-273 kick then drift (stencil values gathered during the previous step)
-        s.vx -= st_kx;
-        s.vy -= st_ky;
-        s.vz -= st_kz;
+        s.vx -= rec_kxy.x;
+        s.vy -= rec_kxy.y;
+        s.vz -= rec_kzk.x;
         s.px += s.vx * a.dt;
         s.py += s.vy * a.dt;
         s.pz += s.vz * a.dt;
@@ -423,7 +461,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         fcz = (double)s.ck;
         cell = (unsigned)(__mul24(__mul24(s.ci, ny) + s.cj, nz) + s.ck);
         // :296-298 absorption coefficient at the new node and the NEXT step's kicks
-        if (alive) gather_record();
+        gather_record();
         // ---- weights (:319-339) -----------------------------------------------------------------
         // Each weight is (Fz * Fy) * Fx * inc with F = (1-d) for the ray's own node along that axis and F = d
         // for the neighbour on the `sign` side (:329-336).  The neighbour lies on the side of the offset's sign
@@ -506,15 +544,6 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
                 q3 = u_eff * (s.vz * a.dt);
             }
         }
-        if (dfr_pending) {                     // scalar branch: last step's retired planes go to HBM now, behind this step's gathers
-            dfr_pending = false;
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                if (dfr.vx[e] != 0.0) { global_add(a, &edep[dfr.nx[e]], dfr.vx[e]); dfr.vx[e] = 0.0; }
-                if (dfr.vy[e] != 0.0) { global_add(a, &edep[dfr.ny[e]], dfr.vy[e]); dfr.vy[e] = 0.0; }
-            }
-            if (!T::BRICK && dfr.vz != 0.0) { global_add(a, &edep[dfr.nz], dfr.vz); dfr.vz = 0.0; }
-        }
         // ---- windows ----------------------------------------------------------------------------------
         inbox = alive;         // the lane deposits into LDS this step ...
         tile_off = 0;          // ... into this tile (offset in doubles)
@@ -535,8 +564,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
             }
             if (out_core != 0ull) {
                 // box A follows the lanes whose home it is
-                bool moved = follow_box<T, true, NC>(a, tileA, oA, memA, lx, ly, lz, lane, edep, sXh, sYh, wc, dfr, NSLOT, a.comp_stride);
-                dfr_pending = dfr_pending || moved;
+                follow_box<T, NC>(a, tileA, oA, memA, lx, ly, lz, lane, edep, sXh, sYh, wc, NSLOT, a.comp_stride);
                 const unsigned long long lost_mask =
                     memA & ~(CBET_BALLOT((unsigned)(lx - oA.x) <= (unsigned)T::SX) & CBET_BALLOT((unsigned)(ly - oA.y) <= (unsigned)T::SY) &
                              CBET_BALLOT((unsigned)(lz - oA.z) <= (unsigned)T::SZ));
@@ -550,8 +578,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
                     // lost ones as well was measured: more misses, 0.63 % against 0.48 % of the ray-steps); an idle B is
                     // re-created around the first lost lane
                     if (b_active) {  // scalar branch
-                        Deferred unused;
-                        follow_box<TB, false, 1>(a, tileB, oB, memB, lx, ly, lz, lane, edep, sXh, sYh, wc, unused, 0, 0);
+                        follow_box<TB, 1>(a, tileB, oB, memB, lx, ly, lz, lane, edep, sXh, sYh, wc, 0, 0);
                     } else if (lost_mask != 0ull) {
                         const int src = __ffsll((long long)lost_mask) - 1;
                         const int sx = __builtin_amdgcn_readlane(lx, src), sy = __builtin_amdgcn_readlane(ly, src),
@@ -585,10 +612,11 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         }
     
         // ---- deposit (:305-311, :341-348) -------------------------------------------------------------
+        await_record();   // the record gathered after the relocation: kappa now, the kicks at the top of the next step
         {
             double inc;
             if (absorb) {
-                inc = kap * s.uray;
+                inc = rec_kzk.y * s.uray;
                 s.uray -= inc;
             } else {
                 inc = s.uray;
@@ -674,13 +702,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         __builtin_amdgcn_wave_barrier();
     }
 
-    // whatever is still in flight or in LDS
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        if (dfr.vx[e] != 0.0) global_add(a, &edep[dfr.nx[e]], dfr.vx[e]);
-        if (dfr.vy[e] != 0.0) global_add(a, &edep[dfr.ny[e]], dfr.vy[e]);
-    }
-    if (!T::BRICK && dfr.vz != 0.0) global_add(a, &edep[dfr.nz], dfr.vz);
+    // whatever is still in LDS
     __syncthreads();
     flush_box<T, NC>(a, tileA, oA, lane, edep, sXh, sYh, wc, NSLOT, a.comp_stride);
     if (b_active) flush_box<TB, 1>(a, tileB, oB, lane, edep, sXh, sYh, wc, 0, 0);
