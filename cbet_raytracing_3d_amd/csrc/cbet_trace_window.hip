@@ -419,8 +419,95 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
     double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;   // CBET = 4: the four field quantities a step deposits
 
     bool slow = true;                        // wave-uniform: this step runs the general (face-aware) forms
-    bool inbox = false;                      // per lane: this step deposits into LDS ...
+    // A step's deposit is issued during the NEXT step, between that step's record gather and its wait (the loop is
+    // rotated: the dependent chain of a step is wait -> kick -> move -> relocate -> gather, everything else fills the
+    // gather's shadow).  What a deposit needs crosses the loop edge: the six per-axis factors, the node indices, the
+    // increment, where it goes.
+    double Fx0 = 0, Fx1 = 0, Fy0 = 0, Fy1 = 0, Fz0 = 0, Fz1 = 0;
+    int X0 = 0, X1 = 0, Y0 = 0, Y1 = 0, Z0 = 0, Z1 = 0;
+    double inc = 0.0;                        // :305-311 the energy the step deposits
+    bool inbox = false;                      // per lane: the deposit goes to LDS ...
     int tile_off = 0;                        // ... into this tile (offset in doubles)
+    bool missed = false;                     // per lane: ... or straight to HBM
+    int own_slot = 0, own_node = 0;          // CBET = 4: the ray's own node, in box A's component tiles / in the grid
+    // The deposit of the step before (:341-348): a_c * increment to the eight nodes, a_c = (Fz * Fy) * Fx.
+    auto deposit_previous = [&]() {
+        const double zy00 = Fz0 * Fy0, zy10 = Fz1 * Fy0, zy01 = Fz0 * Fy1, zy11 = Fz1 * Fy1;
+        // order (x,y,z) = (0,0,0) (1,0,0) (0,0,1) (1,0,1) (0,1,0) (1,1,0) (0,1,1) (1,1,1) -- :341-348 without the flips
+        double wgt[8];
+        wgt[0] = zy00 * Fx0;
+        wgt[1] = zy00 * Fx1;
+        wgt[2] = zy10 * Fx0;
+        wgt[3] = zy10 * Fx1;
+        wgt[4] = zy01 * Fx0;
+        wgt[5] = zy01 * Fx1;
+        wgt[6] = zy11 * Fx0;
+        wgt[7] = zy11 * Fx1;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) wgt[c] = wgt[c] * inc;   // a_c * increment
+        if (inbox) {
+            // slot = (x & XM) * XS + (y & YM) * YS + (z & ZM) with the masks and strides of the lane's tile
+            auto add8 = [&](int xm, int ym, int zm, int xs, int ys, int off) {
+                const int x0 = (X0 & xm) * xs + off, x1 = (X1 & xm) * xs + off;
+                const int y0 = (Y0 & ym) * ys, y1 = (Y1 & ym) * ys;
+                const int z0 = Z0 & zm, z1 = Z1 & zm;
+                const int s00 = x0 + y0, s10 = x1 + y0, s01 = x0 + y1, s11 = x1 + y1;
+                auto add = [&](int slot, double w) {
+                    if (CBET_AUDIT(a, (unsigned)slot < (unsigned)NSLOT))
+                        __hip_atomic_fetch_add(&s_val[slot], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                };
+                add(s00 + z0, wgt[0]);
+                add(s10 + z0, wgt[1]);
+                add(s00 + z1, wgt[2]);
+                add(s10 + z1, wgt[3]);
+                add(s01 + z0, wgt[4]);
+                add(s11 + z0, wgt[5]);
+                add(s01 + z1, wgt[6]);
+                add(s11 + z1, wgt[7]);
+            };
+            if (!b_active) {   // scalar branch: everything goes to box A, compile-time masks and strides
+                add8(T::XM, T::YM, T::ZM, T::XS, T::YS, 0);
+            } else {
+                const bool toB = tile_off != 0;
+                add8(toB ? TB::XM : T::XM, toB ? TB::YM : T::YM, toB ? TB::ZM : T::ZM, toB ? TB::XS : T::XS,
+                     toB ? TB::YS : T::YS, tile_off);
+            }
+        }
+        // window misses: eight atomics, younger than the record gather just issued -- counted for its wait
+        wc.pend += (CBET_BALLOT(missed) != 0ull) ? 8 : 0;
+        if (missed) {
+            const int nX0 = __mul24(X0, sXh), nX1 = __mul24(X1, sXh), nY0 = __mul24(Y0, sYh), nY1 = __mul24(Y1, sYh);
+            global_add(a, &edep[nX0 + nY0 + Z0], wgt[0]);
+            global_add(a, &edep[nX1 + nY0 + Z0], wgt[1]);
+            global_add(a, &edep[nX0 + nY0 + Z1], wgt[2]);
+            global_add(a, &edep[nX1 + nY0 + Z1], wgt[3]);
+            global_add(a, &edep[nX0 + nY1 + Z0], wgt[4]);
+            global_add(a, &edep[nX1 + nY1 + Z0], wgt[5]);
+            global_add(a, &edep[nX0 + nY1 + Z1], wgt[6]);
+            global_add(a, &edep[nX1 + nY1 + Z1], wgt[7]);
+            wc.n_atomics += 8;
+            ++wc.n_miss;
+        }
+        if (CBET == 4) {
+            // Displacement components: the ray's own node only -- box A's tiles, or HBM for a lane of
+            // box B / outside the boxes.
+            if (inbox && tile_off == 0) {
+                if (CBET_AUDIT(a, (unsigned)(own_slot + 2 * T::DT) < (unsigned)NLDS)) {
+                    __hip_atomic_fetch_add(&s_val[own_slot], q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&s_val[own_slot + T::DT], q2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&s_val[own_slot + 2 * T::DT], q3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            } else if (inbox || missed) {
+                global_add(a, &edep[a.comp_stride + own_node], q1);
+                global_add(a, &edep[2 * a.comp_stride + own_node], q2);
+                global_add(a, &edep[3 * a.comp_stride + own_node], q3);
+                wc.n_atomics += 3;
+            }
+        }
+        inbox = false;
+        missed = false;
+    };
+
     for (int tt = 0; tt < a.nt; ++tt) {                        // :207
         if (live == 0ull) break;
         wc.steps_miss += 1u << 16;
@@ -462,6 +549,8 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         cell = (unsigned)(__mul24(__mul24(s.ci, ny) + s.cj, nz) + s.ck);
         // :296-298 absorption coefficient at the new node and the NEXT step's kicks
         gather_record();
+        // ---- the previous step's deposit, in the shadow of the gather -------------------------------------
+        deposit_previous();
         // ---- weights (:319-339) -----------------------------------------------------------------
         // Each weight is (Fz * Fy) * Fx * inc with F = (1-d) for the ray's own node along that axis and F = d
         // for the neighbour on the `sign` side (:329-336).  The neighbour lies on the side of the offset's sign
@@ -475,15 +564,14 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         const double ox = (fx - fcx) - 0.5, oy = (fy - fcy) - 0.5, oz = (fz - fcz) - 0.5;   // :319-321
         const double dm = 1.0 - fabs(ox), dn = 1.0 - fabs(oy), dl = 1.0 - fabs(oz);
         const double ax_own = 1.0 - dm, ay_own = 1.0 - dn, az_own = 1.0 - dl;
-        const double Fx0 = flx ? dm : ax_own, Fx1 = flx ? ax_own : dm;
-        const double Fy0 = fly ? dn : ay_own, Fy1 = fly ? ay_own : dn;
-        const double Fz0 = flz ? dl : az_own, Fz1 = flz ? az_own : dl;
+        Fx0 = flx ? dm : ax_own; Fx1 = flx ? ax_own : dm;
+        Fy0 = fly ? dn : ay_own; Fy1 = fly ? ay_own : dn;
+        Fz0 = flz ? dl : az_own; Fz1 = flz ? az_own : dl;
         // Node indices.  The offsets are xtemp - thisx - 0.5 with |xtemp - thisx| < 0.5001, i.e. negative except in
         // a 1e-4-wide sliver: when they are negative on every axis of every live lane (a ballot of the three sign
         // compares: ~98 % of the wave-steps) the low corner is the own node minus one and the first-visited node
         // depends on the lane's flip bits only.
         int lx, ly, lz;                       // the lane's low corner (haloed)
-        int X0, X1, Y0, Y1, Z0, Z1;
         if (((CBET_BALLOT(!(ox < 0)) | CBET_BALLOT(!(oy < 0)) | CBET_BALLOT(!(oz < 0))) & live) == 0ull) {   // scalar branch
             lx = s.ci;
             ly = s.cj;
@@ -502,18 +590,9 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
             Y0 = ly + (hy ? 1 : 0); Y1 = ly + (hy ? 0 : 1);
             Z0 = lz + (hz ? 1 : 0); Z1 = lz + (hz ? 0 : 1);
         }
-        const double zy00 = Fz0 * Fy0, zy10 = Fz1 * Fy0, zy01 = Fz0 * Fy1, zy11 = Fz1 * Fy1;
-        // order (x,y,z) = (0,0,0) (1,0,0) (0,0,1) (1,0,1) (0,1,0) (1,1,0) (0,1,1) (1,1,1) -- :341-348 without the flips
-        double wgt[8];
-        wgt[0] = zy00 * Fx0;
-        wgt[1] = zy00 * Fx1;
-        wgt[2] = zy10 * Fx0;
-        wgt[3] = zy10 * Fx1;
-        wgt[4] = zy01 * Fx0;
-        wgt[5] = zy01 * Fx1;
-        wgt[6] = zy11 * Fx0;
-        wgt[7] = zy11 * Fx1;
         if (CBET && alive) {   // the gain gathers are memory accesses: live lanes only
+            const double zy00 = Fz0 * Fy0, zy10 = Fz1 * Fy0, zy01 = Fz0 * Fy1, zy11 = Fz1 * Fy1;
+            const double wgt[8] = {zy00 * Fx0, zy00 * Fx1, zy10 * Fx0, zy10 * Fx1, zy01 * Fx0, zy01 * Fx1, zy11 * Fx0, zy11 * Fx1};
             // path length of the step; u_eff = the ray's energy averaged over the step
             double ds = 0.0;
             if (gk || CBET == 4) ds = sqrt(s.vx * s.vx + s.vy * s.vy + s.vz * s.vz) * a.dt;
@@ -542,6 +621,9 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
                 q1 = u_eff * (s.vx * a.dt);
                 q2 = u_eff * (s.vy * a.dt);
                 q3 = u_eff * (s.vz * a.dt);
+                const int hi = s.ci + 1, hj = s.cj + 1, hk = s.ck + 1;
+                own_slot = T::slot_d(hi & T::XM, hj & T::YM, hk & T::ZM) + NSLOT;
+                own_node = __mul24(hi, sXh) + __mul24(hj, sYh) + hk;
             }
         }
         // ---- windows ----------------------------------------------------------------------------------
@@ -611,79 +693,16 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
             }
         }
     
-        // ---- deposit (:305-311, :341-348) -------------------------------------------------------------
+        missed = alive && !inbox;
+        // ---- absorption (:305-311) ---------------------------------------------------------------------
         await_record();   // the record gathered after the relocation: kappa now, the kicks at the top of the next step
-        {
-            double inc;
-            if (absorb) {
-                inc = rec_kzk.y * s.uray;
-                s.uray -= inc;
-            } else {
-                inc = s.uray;
-            }
-            if (CBET == 4) inc = q0;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) wgt[c] = wgt[c] * inc;   // a_c * increment
-            if (inbox) {
-                // slot = (x & XM) * XS + (y & YM) * YS + (z & ZM) with the masks and strides of the lane's tile
-                auto add8 = [&](int xm, int ym, int zm, int xs, int ys, int off) {
-                    const int x0 = (X0 & xm) * xs + off, x1 = (X1 & xm) * xs + off;
-                    const int y0 = (Y0 & ym) * ys, y1 = (Y1 & ym) * ys;
-                    const int z0 = Z0 & zm, z1 = Z1 & zm;
-                    const int s00 = x0 + y0, s10 = x1 + y0, s01 = x0 + y1, s11 = x1 + y1;
-                    auto add = [&](int slot, double w) {
-                        if (CBET_AUDIT(a, (unsigned)slot < (unsigned)NSLOT))
-                            __hip_atomic_fetch_add(&s_val[slot], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    };
-                    add(s00 + z0, wgt[0]);
-                    add(s10 + z0, wgt[1]);
-                    add(s00 + z1, wgt[2]);
-                    add(s10 + z1, wgt[3]);
-                    add(s01 + z0, wgt[4]);
-                    add(s11 + z0, wgt[5]);
-                    add(s01 + z1, wgt[6]);
-                    add(s11 + z1, wgt[7]);
-                };
-                if (!b_active) {   // scalar branch: everything goes to box A, compile-time masks and strides
-                    add8(T::XM, T::YM, T::ZM, T::XS, T::YS, 0);
-                } else {
-                    const bool toB = tile_off != 0;
-                    add8(toB ? TB::XM : T::XM, toB ? TB::YM : T::YM, toB ? TB::ZM : T::ZM, toB ? TB::XS : T::XS,
-                         toB ? TB::YS : T::YS, tile_off);
-                }
-            } else if (alive) {
-                const int nX0 = __mul24(X0, sXh), nX1 = __mul24(X1, sXh), nY0 = __mul24(Y0, sYh), nY1 = __mul24(Y1, sYh);
-                global_add(a, &edep[nX0 + nY0 + Z0], wgt[0]);
-                global_add(a, &edep[nX1 + nY0 + Z0], wgt[1]);
-                global_add(a, &edep[nX0 + nY0 + Z1], wgt[2]);
-                global_add(a, &edep[nX1 + nY0 + Z1], wgt[3]);
-                global_add(a, &edep[nX0 + nY1 + Z0], wgt[4]);
-                global_add(a, &edep[nX1 + nY1 + Z0], wgt[5]);
-                global_add(a, &edep[nX0 + nY1 + Z1], wgt[6]);
-                global_add(a, &edep[nX1 + nY1 + Z1], wgt[7]);
-                wc.n_atomics += 8;
-                ++wc.n_miss;
-            }
-            if (CBET == 4 && alive) {
-                // Displacement components: the ray's own node only -- box A's tiles, or HBM for a lane of
-                // box B / outside the boxes.
-                const int hi = s.ci + 1, hj = s.cj + 1, hk = s.ck + 1;
-                if (inbox && tile_off == 0) {
-                    const int own = T::slot_d(hi & T::XM, hj & T::YM, hk & T::ZM) + NSLOT;
-                    if (CBET_AUDIT(a, (unsigned)(own + 2 * T::DT) < (unsigned)NLDS)) {
-                        __hip_atomic_fetch_add(&s_val[own], q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(&s_val[own + T::DT], q2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(&s_val[own + 2 * T::DT], q3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                } else {
-                    const int own = __mul24(hi, sXh) + __mul24(hj, sYh) + hk;
-                    global_add(a, &edep[a.comp_stride + own], q1);
-                    global_add(a, &edep[2 * a.comp_stride + own], q2);
-                    global_add(a, &edep[3 * a.comp_stride + own], q3);
-                    wc.n_atomics += 3;
-                }
-            }
+        if (absorb) {
+            inc = rec_kzk.y * s.uray;
+            s.uray -= inc;
+        } else {
+            inc = s.uray;
         }
+        if (CBET == 4) inc = q0;
         // ---- termination (:351-356) --------------------------------------------------------------------
         // The six exit planes are compared only when the wave is not deep inside the grid: a lane held by a deep
         // box is more than two cells from every face, far beyond the half cell of :352-354.  Ballots of plain
@@ -702,7 +721,8 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         __builtin_amdgcn_wave_barrier();
     }
 
-    // whatever is still in LDS
+    // the last step's deposit, then whatever is still in LDS
+    deposit_previous();
     __syncthreads();
     flush_box<T, NC>(a, tileA, oA, lane, edep, sXh, sYh, wc, NSLOT, a.comp_stride);
     if (b_active) flush_box<TB, 1>(a, tileB, oB, lane, edep, sXh, sYh, wc, 0, 0);
