@@ -80,7 +80,7 @@ class Counters(C.Structure):
 
 
 MAX_CBET_BEAMS = 64
-DEPOSIT_ENERGY, DEPOSIT_FIELDS = 0, 1   # cbet_trace_cbet's `quantity`
+DEPOSIT_ENERGY, DEPOSIT_FIELDS, DEPOSIT_FIELD_ENERGY = 0, 1, 2   # cbet_trace_cbet's `quantity`
 
 
 class GainParams(C.Structure):
@@ -90,7 +90,7 @@ class GainParams(C.Structure):
         ("iaw", C.c_double),
         ("mach_r0", C.c_double), ("mach_0", C.c_double), ("mach_r1", C.c_double), ("mach_1", C.c_double),
         ("max_exponent", C.c_double), ("relax", C.c_double), ("tolerance", C.c_double),
-        ("max_passes", C.c_int), ("reserved_", C.c_int),
+        ("max_passes", C.c_int), ("direction_passes", C.c_int), ("directions_frozen", C.c_int), ("reserved_", C.c_int),
     ]
 
 

@@ -701,6 +701,7 @@ static int validate_gain(const cbet_params *p, const cbet_gain_params *g)
     if (!(g->iaw > 0.0) || !(g->z_ion > 0.0) || !(g->te_ev > 0.0) || !(g->ti_ev >= 0.0) || !(g->mi_over_me > 0.0))
         return fail(CBET_EINVAL, "bad plasma constants in gain params");
     if (!(g->mach_r1 > g->mach_r0)) return fail(CBET_EINVAL, "mach_r1 must exceed mach_r0");
+    if (g->direction_passes < 1) return fail(CBET_EINVAL, "direction_passes must be >= 1");
     return CBET_OK;
 }
 
@@ -719,6 +720,7 @@ int cbet_gain_params_default(cbet_gain_params *g)
     g->relax = 0.5;           // plain fixed-point iteration (1.0) oscillates with 60 overlapping beams (scripts/cbet_converge.py)
     g->tolerance = 1e-4;
     g->max_passes = 40;
+    g->direction_passes = 1;  // ray paths do not depend on the gain: the direction field of the gain-free first pass is kept
     return CBET_OK;
 }
 
@@ -750,8 +752,8 @@ int cbet_trace_cbet(int b, unsigned nindices, const double *ne3d, const double *
 {
     if (int rc = validate(p)) return rc;
     if (int rc = validate_gain(p, g)) return rc;
-    if (quantity != CBET_DEPOSIT_ENERGY && quantity != CBET_DEPOSIT_FIELDS)
-        return fail(CBET_EINVAL, "quantity must be CBET_DEPOSIT_ENERGY (0) or CBET_DEPOSIT_FIELDS (1)");
+    if (quantity != CBET_DEPOSIT_ENERGY && quantity != CBET_DEPOSIT_FIELDS && quantity != CBET_DEPOSIT_FIELD_ENERGY)
+        return fail(CBET_EINVAL, "quantity must be CBET_DEPOSIT_ENERGY (0), CBET_DEPOSIT_FIELDS (1) or CBET_DEPOSIT_FIELD_ENERGY (2)");
     CbetHooks h;
     h.gain = gain; h.quantity = quantity; h.beam_gain = beam_gain; h.max_exponent = g->max_exponent;
     return trace_impl(b, nindices, ne3d, kappa3d, out, bbeam_norm, beam_norm, pow_r, phase_r, xconst, yconst, zconst,
@@ -817,6 +819,7 @@ static int gain_field_impl(double *fields, const double *ne3d, double *gain, dou
     a.fields = fields; a.ne3d = ne3d ? ne3d : ctx->ne3d; a.gain = gain; a.scratch = scratch; a.change = change;
     a.hx_lo = hx_lo; a.hx_hi = hx_hi;
     a.consume = (consume && scratch) ? 1 : 0;
+    a.frozen = g->directions_frozen ? 1 : 0;
     const long plane = (long)(p->ny + 2) * (p->nz + 2);
     a.store0 = packed ? (long)hx_lo * plane : 0;
     a.bstride = packed ? (long)(hx_hi - hx_lo) * plane : d.edep_size;
@@ -877,16 +880,23 @@ int cbet_cbet_solve(double *te_data_g, double *r_data_g, double *ne_data_g, doub
         pd.beam_lo = 0; pd.beam_hi = p->nbeams;
         // the fields are cleared once; every gain update hands them back zeroed (GainArgs.consume)
         CBET_HIP(hipMemsetAsync(fields, 0, 4 * nb * hsize * sizeof(double), s));
+        cbet_gain_params gg = *g;
         for (int pass = 0; pass < g->max_passes; ++pass) {
+            // the first direction_passes passes deposit all four fields and build k; later ones the energy field only
+            const bool full = pass < g->direction_passes;
+            if (full && pass > 0)   // a second direction-building pass accumulates into cleared direction entries
+                CBET_HIP(hipMemsetAsync(fields + nb * hsize, 0, 3 * nb * hsize * sizeof(double), s));
             {
                 CbetHooks h;
-                h.gain = pass == 0 ? nullptr : gain; h.quantity = CBET_DEPOSIT_FIELDS; h.max_exponent = g->max_exponent;
+                h.gain = pass == 0 ? nullptr : gain; h.quantity = full ? CBET_DEPOSIT_FIELDS : CBET_DEPOSIT_FIELD_ENERGY;
+                h.max_exponent = g->max_exponent;
                 if (int r = trace_impl(0, (unsigned)d.nindices, nullptr, nullptr, fields, bbeam_norm, beam_norm, pow_r, phase_r,
                                        d.xconst, d.yconst, d.zconst, &pf, ctx, stream, h))
                     return r;
             }
             CBET_HIP(hipMemsetAsync(change, 0, 2 * sizeof(double), s));
-            if (int r = gain_field_impl(fields, nullptr, gain, scratch, change, 0, p->nx + 2, false, p, g, ctx, stream, true)) return r;
+            gg.directions_frozen = full ? 0 : 1;
+            if (int r = gain_field_impl(fields, nullptr, gain, scratch, change, 0, p->nx + 2, false, p, &gg, ctx, stream, true)) return r;
             double hc[2];
             CBET_HIP(hipMemcpyAsync(hc, change, sizeof hc, hipMemcpyDeviceToHost, s));
             CBET_HIP(hipStreamSynchronize(s));

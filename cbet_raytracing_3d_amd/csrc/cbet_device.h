@@ -91,7 +91,7 @@ struct TraceArgs {
     int grid_beam0;                         // beam whose grid comes first in a beam-resolved `edep` / in `gain` (cbet_params.grid_beam0)
     const double *gain;                     // [grid beams][(n+2)^3] gain coefficient on the deposit grid, 1/cm
     long hsize;                             // (nx+2)(ny+2)(nz+2)
-    int quantity;                           // 0: deposit the absorbed energy; 1: the four field components (fused field pass)
+    int quantity;                           // 0: deposit the absorbed energy; 1: the four field components (fused field pass); 2: the energy field alone
     long comp_stride;                       // field pass: doubles between the component arrays (nbeams * hsize)
     double max_exponent;                    // clamp on |K ds| per step (<= 1)
     double *beam_gain;                      // [nbeams] energy gained through CBET, or NULL
@@ -112,7 +112,8 @@ struct GainArgs {
     double *change;                         // device {sum |new-old|, sum |new|} accumulators, or NULL
     int hx_lo, hx_hi;                       // planes [hx_lo, hx_hi) of the haloed grid to update (a rank's slab; 0 .. nx+2 = all)
     // storage of fields / gain / scratch: entry of cell h of beam b at [b * bstride + h - store0] (+ component * nbeams * bstride)
-    int consume;                            // symmetric kernel: leave the fields zeroed instead of normalised (the solve loop's next pass accumulates into them)
+    int consume;                            // symmetric kernel: leave the energy entries zeroed instead of normalised (the solve loop's next pass accumulates into them)
+    int frozen;                             // the direction entries already hold k (cbet_gain_params.directions_frozen)
     long store0, bstride;                   // whole-grid arrays: 0, hsize; slab-packed arrays: hx_lo * (ny+2)(nz+2), slab entries
 };
 

@@ -44,12 +44,39 @@ __device__ __forceinline__ CellState cell_state(const GainArgs &a, long h)
     return c;
 }
 
+// Phase 1 of both gain kernels for one beam's entry of a cell that the beam's rays touched (E != 0): the deposited
+// (E, Dx, Dy, Dz) become (I, kx, ky, kz) in place.  I = E / (group speed x dt) where the beam is present (E > 0,
+// sub-critical plasma, a direction known), else 0; k = |k| D / |D|.  With GainArgs.frozen the three direction
+// entries already hold k -- written by an earlier call on the fields of the gain-free first pass -- and only the
+// energy entry is read and replaced.
+__device__ __forceinline__ void normalise_entry(const GainArgs &a, const CellState &c, double kmag, double ds_node,
+                                                double E, double *fI, double *fx, double *fy, double *fz, long o)
+{
+    double I = 0.0;
+    if (a.frozen) {
+        const double kx = fx[o], ky = fy[o], kz = fz[o];
+        if (E > 0.0 && c.eps > 0.0 && (kx != 0.0 || ky != 0.0 || kz != 0.0)) I = E / ds_node;
+        fI[o] = I;
+        return;
+    }
+    const double ax = fx[o], ay = fy[o], az = fz[o];
+    const double dn = sqrt(ax * ax + ay * ay + az * az);
+    double kx = 0.0, ky = 0.0, kz = 0.0;
+    if (c.eps > 0.0 && dn > 0.0) {
+        if (E > 0.0) I = E / ds_node;
+        kx = kmag * (ax / dn);
+        ky = kmag * (ay / dn);
+        kz = kmag * (az / dn);
+    }
+    fI[o] = I; fx[o] = kx; fy[o] = ky; fz[o] = kz;
+}
+
 // fields (E, Dx, Dy, Dz) -> gain coefficient, one wavefront per 2 x 4 x 8 brick of deposit-grid cells
 // (z fastest: every load is eight 64-B runs).  A compact brick keeps the set of beams present
 // ANYWHERE in the wave small -- the beam loops below run over that set (a ballot-built bit mask),
 // and a 64-cell z-row crosses several times more beams than a brick does.
-//   phase 1: for every beam present in a lane's cell, normalise in place to (I, kx, ky, kz);
-//            entries of absent beams (E <= 0) are left as deposited and never used.
+//   phase 1: every entry a beam's rays touched (E != 0) is normalised in place to (I, kx, ky, kz), I = 0 where the
+//            beam is not present (E <= 0); with GainArgs.frozen only the energy entry (normalise_entry).
 //   phase 2: K_i = sum_{j != i} G_ij I_j, beams in increasing order; gain <- gain + relax (K - gain),
 //            stored only where it changes.
 __global__ void __launch_bounds__(256) k_gain_field(const GainArgs a)
@@ -81,21 +108,9 @@ __global__ void __launch_bounds__(256) k_gain_field(const GainArgs a)
         for (int b = 0; b < a.nbeams; ++b) {
             const long o = (long)b * hsize;
             const double E = valid ? fI[o] : 0.0;
-            const bool pres = E > 0.0;
-            if (__builtin_amdgcn_ballot_w64(pres) == 0ull) continue;
-            mask |= 1ull << b;
-            if (pres) {
-                const double ax = fx[o], ay = fy[o], az = fz[o];
-                const double dn = sqrt(ax * ax + ay * ay + az * az);
-                double I = 0.0, kx = 0.0, ky = 0.0, kz = 0.0;
-                if (c.eps > 0.0 && dn > 0.0) {
-                    I = E / ds_node;
-                    kx = kmag * (ax / dn);
-                    ky = kmag * (ay / dn);
-                    kz = kmag * (az / dn);
-                }
-                fI[o] = I; fx[o] = kx; fy[o] = ky; fz[o] = kz;
-            }
+            if (__builtin_amdgcn_ballot_w64(E != 0.0) == 0ull) continue;   // no ray of this beam came near the brick
+            if (__builtin_amdgcn_ballot_w64(E > 0.0) != 0ull) mask |= 1ull << b;
+            if (E != 0.0) normalise_entry(a, c, kmag, ds_node, E, fI, fx, fy, fz, o);
         }
         const double pref = c.eps > 0.0 ? a.gain_const * c.frac * (1.0 / a.iaw) / c.rt : 0.0;
         for (int bi = 0; bi < a.nbeams; ++bi) {
@@ -200,27 +215,11 @@ __global__ void __launch_bounds__(256) k_gain_field_sym(const GainArgs a)
         for (int b = 0; b < a.nbeams; ++b) {  // phase 1: as k_gain_field, plus the scratch sums start at zero
             const long o = (long)b * hsize;
             const double E = valid ? fI[o] : 0.0;
-            const bool pres = E > 0.0;
-            if (__builtin_amdgcn_ballot_w64(pres) == 0ull) {
-                // a beam absent from the whole brick; consume: clear what little the deposit weights' negative
-                // fringe may have left here (see the end of the brick)
-                if (a.consume && E != 0.0) { fI[o] = 0.0; fx[o] = 0.0; fy[o] = 0.0; fz[o] = 0.0; }
-                continue;
-            }
+            if (__builtin_amdgcn_ballot_w64(E != 0.0) == 0ull) continue;   // no ray of this beam came near the brick
+            if (E != 0.0) normalise_entry(a, c, kmag, ds_node, E, fI, fx, fy, fz, o);   // also clears a non-positive E
+            if (__builtin_amdgcn_ballot_w64(E > 0.0) == 0ull) continue;
             mask |= 1ull << b;
             if (valid) raw[o] = 0.0;
-            if (pres) {
-                const double ax = fx[o], ay = fy[o], az = fz[o];
-                const double dn = sqrt(ax * ax + ay * ay + az * az);
-                double I = 0.0, kx = 0.0, ky = 0.0, kz = 0.0;
-                if (c.eps > 0.0 && dn > 0.0) {
-                    I = E / ds_node;
-                    kx = kmag * (ax / dn);
-                    ky = kmag * (ay / dn);
-                    kz = kmag * (az / dn);
-                }
-                fI[o] = I; fx[o] = kx; fy[o] = ky; fz[o] = kz;
-            }
         }
         const double pref = (valid && c.eps > 0.0) ? a.gain_const * c.frac * (1.0 / a.iaw) / c.rt : 0.0;
         auto load_tile = [&](unsigned long long &m, int (&id)[GT], BeamAtCell (&bm)[GT]) {
@@ -290,13 +289,14 @@ __global__ void __launch_bounds__(256) k_gain_field_sym(const GainArgs a)
                 }
         }
         if (a.consume && valid) {
-            // consume: the fields have done their work -- hand them back zeroed, so that the next field pass can
-            // accumulate into them without a 33 GB memset in between (the lines were just written, they are in L2)
+            // consume: the energy entries have done their work -- hand them back zeroed, so that the next field pass
+            // can accumulate into them without a memset in between (the lines were just written, they are in L2);
+            // the direction entries stay: later passes reuse them (GainArgs.frozen)
             unsigned long long mz = mask;
             while (mz != 0ull) {
                 const long o = (long)(__ffsll((long long)mz) - 1) * hsize;
                 mz &= mz - 1;
-                fI[o] = 0.0; fx[o] = 0.0; fy[o] = 0.0; fz[o] = 0.0;
+                fI[o] = 0.0;
             }
         }
         if (valid) {  // beams absent from the whole brick relax towards zero

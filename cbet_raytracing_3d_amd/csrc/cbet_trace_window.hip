@@ -25,7 +25,7 @@
 // Template parameters: WZ = z extent of a tile (16: aligned z-bricks; 8: single z-planes, used by the
 // CBET field pass whose three extra component tiles would not fit otherwise); GENERIC = run-time
 // absorption flag and 64-bit table indexing (grids of >= 2^32 table bytes, bookkeeping mode) instead
-// of the compiled-in common case; CBET = 0 none, 1 gain hooks, 4 fused four-component field pass
+// of the compiled-in common case; CBET = 0 none, 1 gain hooks, 2 gain hooks + the energy field deposited, 4 fused four-component field pass
 // (no reference counterpart: DESIGN.md section 9).
 #include <hip/hip_runtime.h>
 
@@ -595,7 +595,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
             const double wgt[8] = {zy00 * Fx0, zy00 * Fx1, zy10 * Fx0, zy10 * Fx1, zy01 * Fx0, zy01 * Fx1, zy11 * Fx0, zy11 * Fx1};
             // path length of the step; u_eff = the ray's energy averaged over the step
             double ds = 0.0;
-            if (gk || CBET == 4) ds = sqrt(s.vx * s.vx + s.vy * s.vy + s.vz * s.vz) * a.dt;
+            if (gk || CBET >= 2) ds = sqrt(s.vx * s.vx + s.vy * s.vy + s.vz * s.vz) * a.dt;
             double u_eff = s.uray;
             if (gk) {
                 // K at the eight deposit nodes, weighted like the deposit.  The pairwise tree makes the
@@ -616,6 +616,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
                 gained += dg;
                 s.uray = s.uray + dg;
             }
+            if (CBET == 2) q0 = u_eff * ds;
             if (CBET == 4) {
                 q0 = u_eff * ds;
                 q1 = u_eff * (s.vx * a.dt);
@@ -702,7 +703,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         } else {
             inc = s.uray;
         }
-        if (CBET == 4) inc = q0;
+        if (CBET >= 2) inc = q0;   // field passes deposit energy x path length
         // ---- termination (:351-356) --------------------------------------------------------------------
         // The six exit planes are compared only when the wave is not deep inside the grid: a lane held by a deep
         // box is more than two cells from every face, far beyond the half cell of :352-354.  Ballots of plain
@@ -758,9 +759,12 @@ hipError_t launch_trace_window(const TraceArgs &a, bool force_idx64, hipStream_t
     // the step records are addressed with 64 bits always; GENERIC is needed for bookkeeping mode and, with the CBET
     // hooks, for gain grids of >= 2^32 bytes (32-bit byte offsets otherwise)
     const bool generic = force_idx64 || (a.gain && 8ull * (unsigned long long)a.hsize >= (1ull << 32)) || a.absorption != 1;
-    if (a.quantity != 0) {  // the fused four-component field pass (single z-planes: four tiles per wave must fit)
+    if (a.quantity == 1) {  // the fused four-component field pass (single z-planes: four tiles per wave must fit)
         if (generic) hipLaunchKernelGGL((k_trace_window<8, true, 4>), grid, block, 0, stream, a);
         else hipLaunchKernelGGL((k_trace_window<8, false, 4>), grid, block, 0, stream, a);
+    } else if (a.quantity == 2) {  // the energy field alone: the shipped kernel's windows, energy x path length deposited
+        if (generic) hipLaunchKernelGGL((k_trace_window<16, true, 2>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((k_trace_window<16, false, 2>), grid, block, 0, stream, a);
     } else if (a.gain || a.beam_gain) {
         if (generic) hipLaunchKernelGGL((k_trace_window<16, true, 1>), grid, block, 0, stream, a);
         else hipLaunchKernelGGL((k_trace_window<16, false, 1>), grid, block, 0, stream, a);

@@ -90,11 +90,15 @@ class RayTracer:
                     shard_count=1, ne3d=None, kappa3d=None, beam_lo=0, beam_hi=None, grid_beam0=0, grid_beams=0):
         """One trace with the CBET hooks on torch's current stream (node tables must be filled:
         tabulate(), or pass ne3d / kappa3d).  fields=False: deposit the absorbed energy into `out`
-        ((n+2)^3 grid or a grid per beam); fields=True: the fused field pass, `out` = new_fields().
+        ((n+2)^3 grid or a grid per beam); fields=True: the fused field pass, `out` = new_fields();
+        fields="energy": the energy field alone, `out` = new_fields()[0] (a grid per beam).
         grid_beams > 0: the beam-resolved arrays (`out` when it is per beam, `gain`) hold only the grids of
         beams [grid_beam0, grid_beam0 + grid_beams) (cbet_params.grid_beam0 / grid_beams)."""
         ngrids = grid_beams if grid_beams > 0 else self.params.nbeams
-        if fields:
+        if fields == "energy":
+            want = (ngrids,) + self.grid_shape
+            per_beam = True
+        elif fields:
             want = (4, ngrids) + self.grid_shape
             per_beam = True
         else:
@@ -111,7 +115,8 @@ class RayTracer:
                              grid_beam0=grid_beam0, grid_beams=grid_beams)
         d = self.derived
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        api.trace_cbet(0, d.nindices, ne3d, kappa3d, gain, api.DEPOSIT_FIELDS if fields else api.DEPOSIT_ENERGY, out,
+        quantity = api.DEPOSIT_FIELD_ENERGY if fields == "energy" else (api.DEPOSIT_FIELDS if fields else api.DEPOSIT_ENERGY)
+        api.trace_cbet(0, d.nindices, ne3d, kappa3d, gain, quantity, out,
                        beam_gain, self.d_bbeam_norm, self.d_beam_norm, self.d_pow_r, self.d_phase_r, d.xconst,
                        d.yconst, d.zconst, p, gain_params, self.ctx, stream)
         return out
@@ -120,13 +125,14 @@ class RayTracer:
         """Zeroed [4][nbeams][(n+2)^3] field array (energy x path length, energy x displacement x/y/z)."""
         return torch.zeros((4, self.params.nbeams) + self.grid_shape, dtype=torch.float64, device=self.device)
 
-    def gain_field(self, fields, gain, gain_params, change=None, ne3d=None, scratch=None, x_lo=0, x_hi=None):
+    def gain_field(self, fields, gain, gain_params, change=None, ne3d=None, scratch=None, x_lo=0, x_hi=None, frozen=False):
         """Normalise `fields` in place and relax `gain` towards the gain coefficient they imply.
         scratch: a work array shaped like `gain` (each beam pair evaluated once), or None (ordered kernel).
-        x_lo, x_hi: only the planes [x_lo, x_hi) of the deposit grid (one rank's slab)."""
+        x_lo, x_hi: only the planes [x_lo, x_hi) of the deposit grid (one rank's slab).
+        frozen: fields[1:4] already hold k from an earlier call; only fields[0] is read and normalised."""
         stream = torch.cuda.current_stream(self.device).cuda_stream
         api.gain_field_slab(fields, ne3d, gain, scratch, change, x_lo, self.grid_shape[0] if x_hi is None else x_hi,
-                            self.params, gain_params, self.ctx, stream)
+                            self.params, _frozen(gain_params, frozen), self.ctx, stream)
         return gain
 
     def cbet_solve(self, edep, gain_params, rank=0, world_size=1, group=None, fields=None, gain=None, slabs=False):
@@ -314,15 +320,16 @@ class _DeviceCbetEngine:
         tr.tabulate()
         self.gain.zero_()
 
-    def field_passes(self, use_gain, shard_index, shard_count):
-        self.fields.zero_()
-        self.tr.launch_cbet(self.fields, self.gp, fields=True, gain=self.gain if use_gain else None,
-                            shard_index=shard_index, shard_count=shard_count)
+    def field_passes(self, use_gain, shard_index, shard_count, full=True):
+        """full: all four fields; else the energy field (fields[0]) alone -- fields[1:4] keep the k of the last full pass."""
+        (self.fields if full else self.fields[0]).zero_()
+        self.tr.launch_cbet(self.fields if full else self.fields[0], self.gp, fields=True if full else "energy",
+                            gain=self.gain if use_gain else None, shard_index=shard_index, shard_count=shard_count)
         return self.fields
 
-    def update_gain(self, fields):
+    def update_gain(self, fields, frozen=False):
         self.change.zero_()
-        self.tr.gain_field(fields, self.gain, self.gp, self.change, scratch=self.scratch)
+        self.tr.gain_field(fields, self.gain, self.gp, self.change, scratch=self.scratch, frozen=frozen)
         return self.change
 
     def deposit(self, shard_index, shard_count):
@@ -348,19 +355,20 @@ class _DeviceCbetEngine:
     def slab_bytes(self):
         return 8 * sum(t.numel() for t in (self.own_fields, self.gain_own, self.slab_fields, self.gain_slab, self.scratch_slab))
 
-    def field_passes_beams(self, use_gain):
-        self.own_fields.zero_()
+    def field_passes_beams(self, use_gain, full=True):
+        out = self.own_fields if full else self.own_fields[0]
+        out.zero_()
         if self.b1 > self.b0:
-            self.tr.launch_cbet(self.own_fields, self.gp, fields=True, gain=self.gain_own if use_gain else None,
+            self.tr.launch_cbet(out, self.gp, fields=True if full else "energy", gain=self.gain_own if use_gain else None,
                                 beam_lo=self.b0, beam_hi=self.b1, grid_beam0=self.b0, grid_beams=self.b1 - self.b0)
         return self.own_fields
 
-    def update_gain_slab(self):
+    def update_gain_slab(self, frozen=False):
         self.change.zero_()
         if self.x1 > self.x0:
             stream = torch.cuda.current_stream(self.tr.device).cuda_stream
             api.gain_field_packed(self.slab_fields, None, self.gain_slab, self.scratch_slab, self.change, self.x0, self.x1,
-                                  self.tr.params, self.gp, self.tr.ctx, stream)
+                                  self.tr.params, _frozen(self.gp, frozen), self.tr.ctx, stream)
         return self.change
 
     def deposit_beams(self):
@@ -369,6 +377,15 @@ class _DeviceCbetEngine:
             self.tr.launch_cbet(self.edep, self.gp, gain=self.gain_own, beam_gain=self.beam_gain, beam_lo=self.b0,
                                 beam_hi=self.b1, grid_beam0=self.b0, grid_beams=self.b1 - self.b0)
         return self.beam_gain
+
+
+def _frozen(gain_params, frozen):
+    """gain_params with directions_frozen set as asked (a copy when it has to change)."""
+    if bool(gain_params.directions_frozen) == bool(frozen):
+        return gain_params
+    g = type(gain_params).from_buffer_copy(gain_params)
+    g.directions_frozen = 1 if frozen else 0
+    return g
 
 
 def _agree(t, group, world_size):
@@ -386,23 +403,26 @@ def _agree(t, group, world_size):
 def cbet_fixed_point(engine, gain_params, rank=0, world_size=1, group=None):
     """The CBET fixed-point iteration over `world_size` ranks (parity unpinned).
 
-    Every pass: each rank deposits the four field components of ITS share of the ray bundles (the plain
-    pass's interleaved sharding), the fields are summed over ranks with one all-reduce, and every rank
-    updates the full gain coefficient from them (redundantly -- it needs all of it for its own rays).
+    Every pass: each rank deposits the fields of ITS share of the ray bundles (the plain pass's sharding) -- all four
+    in the first gain_params.direction_passes passes, which build the direction field k, the energy field alone
+    afterwards (gain changes ray energies, not ray paths: k of the gain-free pass is kept) --, the deposited fields
+    are summed over ranks with one all-reduce, and every rank updates the full gain coefficient from them
+    (redundantly -- it needs all of it for its own rays).
     Stops when sum |dK| / sum |K| < tolerance (rank 0's value, broadcast), then runs the deposition pass and
     all-reduces the per-beam energy balance.  `engine` supplies the per-rank compute:
-        begin(); field_passes(use_gain, shard_index, shard_count) -> fields tensor;
-        update_gain(fields) -> tensor {sum |dK|, sum |K|}; deposit(shard_index, shard_count) -> beam_gain tensor
+        begin(); field_passes(use_gain, shard_index, shard_count, full) -> fields tensor;
+        update_gain(fields, frozen) -> tensor {sum |dK|, sum |K|}; deposit(shard_index, shard_count) -> beam_gain tensor
     (the device engine is RayTracer.cbet_solve's; the CPU tests drive this loop with an oracle engine).
     Returns {passes, converged, change, beam_gain, imbalance}."""
     si, sc = shard_of_rank(rank, world_size)
     engine.begin()
     rep = {"passes": 0, "converged": False, "change": float("inf")}
     for it in range(gain_params.max_passes):
-        fields = engine.field_passes(it > 0, si, sc)
+        full = it < gain_params.direction_passes
+        fields = engine.field_passes(it > 0, si, sc, full)
         if world_size > 1:
-            allreduce_grid(fields, group)
-        ch = _agree(engine.update_gain(fields), group, world_size)
+            allreduce_grid(fields if full else fields[0], group)
+        ch = _agree(engine.update_gain(fields, not full), group, world_size)
         rep["passes"] = it + 1
         rep["change"] = float(ch[0] / ch[1]) if float(ch[1]) > 0 else 0.0
         if rep["change"] < gain_params.tolerance:
@@ -472,9 +492,10 @@ def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_s
     slab (all-to-all, (W-1)/W of own_fields); (2) each rank updates the gain of ALL beams on its slab; (3) it sends
     every rank the gain of that rank's beams over its slab (all-to-all, gain_slab); (4) two scalars are
     all-reduced for the convergence measure and rank 0's copy decides.  At 256^3 / 60 beams / 8 ranks that is
-    3.6 GB + 0.9 GB sent per rank and pass, against 58 GB of ring traffic per rank for the all-reduce loop.
-    `engine`: begin_slabs(b0, b1, x0, x1); field_passes_beams(use_gain) -> own_fields; attributes slab_fields,
-    gain_slab, gain_own; update_gain_slab() -> tensor {sum |dK|, sum |K|} over the slab; deposit_beams() ->
+    3.6 GB + 0.9 GB sent per rank in a direction-building pass (the first) and 0.9 GB + 0.9 GB in every later one
+    (energy field only), against 58 / 14 GB of ring traffic per rank for the all-reduce loop.
+    `engine`: begin_slabs(b0, b1, x0, x1); field_passes_beams(use_gain, full) -> own_fields; attributes slab_fields,
+    gain_slab, gain_own; update_gain_slab(frozen) -> tensor {sum |dK|, sum |K|} over the slab; deposit_beams() ->
     beam_gain.  The deposition grid is left un-reduced (allreduce_grid / reduce_scatter_grid)."""
     import torch.distributed as dist
     beams, slabs = _parts(nbeams, world_size), _parts(nx_halo, world_size)
@@ -482,11 +503,13 @@ def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_s
     engine.begin_slabs(b0, b1, x0, x1)
     rep = {"passes": 0, "converged": False, "change": float("inf")}
     for it in range(gain_params.max_passes):
-        own = engine.field_passes_beams(it > 0)
+        full = it < gain_params.direction_passes
+        comps = slice(None) if full else slice(0, 1)    # after the direction-building passes only the energy field moves
+        own = engine.field_passes_beams(it > 0, full)
         # my beams' fields over slab s -> rank s; rank q's beams over my slab <- rank q
-        _exchange(own, lambda s: (slice(None), slice(None), slice(*slabs[s])),
-                  engine.slab_fields, lambda q: (slice(None), slice(*beams[q])), rank, world_size, group)
-        ch = engine.update_gain_slab()
+        _exchange(own, lambda s: (comps, slice(None), slice(*slabs[s])),
+                  engine.slab_fields, lambda q: (comps, slice(*beams[q])), rank, world_size, group)
+        ch = engine.update_gain_slab(not full)
         if world_size > 1:
             if ch.is_cuda and dist.get_backend(group) != "nccl":
                 host = ch.cpu()

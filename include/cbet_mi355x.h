@@ -288,6 +288,11 @@ typedef struct cbet_gain_params {
     double relax;          /* K <- K + relax (K_raw - K) between passes, 0 < relax <= 1          */
     double tolerance;      /* cbet_cbet_solve stops when sum |dK| / sum |K| falls below it       */
     int max_passes;        /* ... or after this many field passes                                */
+    int direction_passes;  /* the first direction_passes (>= 1, default 1) field passes deposit all four fields and
+                              build the direction field k; later passes deposit the energy field alone and reuse k --
+                              gain changes ray energies, not ray paths, so k of the gain-free first pass is kept      */
+    int directions_frozen; /* cbet_gain_field*: 1 = the three direction components of `fields` already hold k (an
+                              earlier call normalised them): only the energy component is read and normalised       */
     int reserved_;
 } cbet_gain_params;
 
@@ -311,6 +316,8 @@ int cbet_gain_constants(const cbet_params *p, const cbet_gain_params *g, double 
  * nodes with the deposit weights and multiplies the ray's energy by exp(K |v| dt) before absorption.
  * quantity says what a step deposits into `out`:
  *   CBET_DEPOSIT_ENERGY  the absorbed energy (the reference's edep; `out` as for cbet_trace_nodes);
+ *   CBET_DEPOSIT_FIELD_ENERGY  the first of those four fields alone (out is [nbeams][(n+2)^3], i.e. the head of a
+ *                        fields array): what every field pass after the direction-building ones deposits;
  *   CBET_DEPOSIT_FIELDS  the four per-beam fields the gain needs, in ONE trace: out is
  *       [4][nbeams][(n+2)^3] -- component 0 the step-averaged ray energy x path length, spread over the
  *       eight deposit nodes with the deposit weights; components 1..3 that energy x the step's
@@ -319,6 +326,7 @@ int cbet_gain_constants(const cbet_params *p, const cbet_gain_params *g, double 
  */
 #define CBET_DEPOSIT_ENERGY 0
 #define CBET_DEPOSIT_FIELDS 1
+#define CBET_DEPOSIT_FIELD_ENERGY 2
 int cbet_trace_cbet(int b, unsigned nindices, const double *ne3d, const double *kappa3d,
                     const double *gain, int quantity, double *out, double *beam_gain,
                     const double *bbeam_norm, const double *beam_norm, const double *pow_r,
@@ -326,8 +334,9 @@ int cbet_trace_cbet(int b, unsigned nindices, const double *ne3d, const double *
                     const cbet_params *p, const cbet_gain_params *g, cbet_context *ctx, void *stream);
 /*
  * fields: device [4][nbeams][(n+2)^3] = what a CBET_DEPOSIT_FIELDS pass deposited;
- * normalised IN PLACE to (intensity, k_x, k_y, k_z) wherever the beam is present (energy > 0; entries
- * of absent beams are left as deposited).  gain: device [nbeams][(n+2)^3], updated to
+ * normalised IN PLACE to (intensity, k_x, k_y, k_z) wherever the beam's rays deposited (intensity 0 where the
+ * energy is not positive); with g->directions_frozen the k entries are taken as they are and only the energy
+ * entries are read and normalised.  gain: device [nbeams][(n+2)^3], updated to
  * gain + relax (K - gain).  change: device double[2], ADDED into: {sum |new - old|, sum |new|}
  * (may be NULL).  scratch: device [nbeams][(n+2)^3] work array (contents ignored and overwritten) --
  * with it every unordered beam pair is evaluated once; NULL selects the ordered kernel (twice the

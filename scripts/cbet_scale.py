@@ -34,6 +34,10 @@ t = timed(lambda: tr.gain_field(fields, gain, gp, change, scratch=scratch))
 print("normalise + gain kernels: %.2f ms; K max %.3g 1/cm" % (t, float(gain.abs().max())), flush=True)
 fields.zero_()
 print("field pass, with gain: %.2f ms" % timed(lambda: tr.launch_cbet(fields, gp, fields=True, gain=gain)), flush=True)
+fields[0].zero_()
+print("energy-field pass (every pass after the first), with gain: %.2f ms" % timed(lambda: tr.launch_cbet(fields[0], gp, fields="energy", gain=gain)), flush=True)
+t = timed(lambda: tr.gain_field(fields, gain, gp, change, scratch=scratch, frozen=True))
+print("gain kernel, frozen directions: %.2f ms" % t, flush=True)
 e.zero_()
 print("deposition pass with gain: %.2f ms" % timed(lambda: tr.launch_cbet(e, gp, gain=gain)), flush=True)
 del fields, gain, scratch

@@ -118,14 +118,14 @@ def test_gain_params_and_constants_host_side(api, oracle, case):
     og = case["g"]
     for name in ("z_ion", "te_ev", "ti_ev", "mi_over_me", "iaw", "mach_r0", "mach_0", "mach_r1", "mach_1", "max_exponent"):
         assert getattr(g, name) == getattr(og, name), name
-    assert (g.relax, g.tolerance, g.max_passes) == (0.5, 1e-4, 40)
+    assert (g.relax, g.tolerance, g.max_passes, g.direction_passes, g.directions_frozen) == (0.5, 1e-4, 40, 1, 0)
     p = api.default_params(N, nbeams=len(BEAMS))
     c1, cs, gc = api.gain_constants(p, g)
     assert (c1, cs, gc) == oracle.gain_constants(case["cfg"], og)
     assert 3.9e7 < cs < 4.1e7                           # def.cuh:113 "approx. 4e7 cm/s in this example"
     assert api.cbet_workspace_bytes(p) == (6 * len(BEAMS) * (N + 2) ** 3 + 2 + api.MAX_CBET_BEAMS) * 8
     for bad in (dict(max_exponent=0.0), dict(max_exponent=1.5), dict(relax=0.0), dict(relax=1.01), dict(iaw=0.0),
-                dict(mach_r1=0.01)):
+                dict(mach_r1=0.01), dict(direction_passes=0)):
         with pytest.raises(api.CbetError) as ei:
             api.gain_constants(p, api.default_gain_params(**bad))
         assert ei.value.code == api.EINVAL
@@ -169,12 +169,19 @@ class _OracleEngine:
     def _items(self, si, sc):
         return self.api.shard_items(self.p, self.nb, si, sc)
 
-    def field_passes(self, use_gain, si, sc):
+    def field_passes(self, use_gain, si, sc, full=True):
+        # full: all four fields; else the energy field alone -- the direction fields of the last full pass are kept
+        # (the oracle's gain_field normalises the raw D of that pass again each time: the same k)
+        qs = (1, 2, 3, 4) if full else (1,)
         F = [self.O.trace_cbet(self.cfg, self.g, self.bn, self.ne3d, self.kap, gain=self.gain if use_gain else None,
-                               quantity=q, per_beam=True, nthreads=2, items=self._items(si, sc))[0] for q in (1, 2, 3, 4)]
-        return torch.from_numpy(np.stack(F))
+                               quantity=q, per_beam=True, nthreads=2, items=self._items(si, sc))[0] for q in qs]
+        if full:
+            self.fields = torch.from_numpy(np.stack(F))
+        else:
+            self.fields[0] = torch.from_numpy(F[0])
+        return self.fields
 
-    def update_gain(self, fields):
+    def update_gain(self, fields, frozen=False):
         self.gain, ch = self.O.gain_field(self.cfg, self.g, fields.numpy(), self.ne3d, relax=1.0, gain=self.gain, nthreads=2)
         return torch.tensor(ch, dtype=torch.float64)
 
@@ -205,13 +212,18 @@ class _OracleEngine:
         g[self.b0:self.b1] = self.gain_own.numpy()
         return g
 
-    def field_passes_beams(self, use_gain):
+    def field_passes_beams(self, use_gain, full=True):
+        qs = (1, 2, 3, 4) if full else (1,)
         F = [self.O.trace_cbet(self.cfg, self.g, self.bn, self.ne3d, self.kap, gain=self._full_gain() if use_gain else None,
                                quantity=q, per_beam=True, nthreads=2, items=self._beam_items())[0][self.b0:self.b1]
-             for q in (1, 2, 3, 4)]
-        return torch.from_numpy(np.stack(F))
+             for q in qs]
+        if full:
+            self.own_fields = torch.from_numpy(np.stack(F))
+        else:
+            self.own_fields[0] = torch.from_numpy(np.ascontiguousarray(F[0]))
+        return self.own_fields
 
-    def update_gain_slab(self):
+    def update_gain_slab(self, frozen=False):
         # the oracle updates whole grids: embed the slab (zero fields elsewhere), keep the slab of the result
         gs = self.O.grid_shape(self.cfg)
         F = np.zeros((4, self.nb) + gs)

@@ -96,6 +96,16 @@ def test_field_pass_matches_oracle(api, setup, torch_cuda):
     f0 = tr.new_fields()
     tr.launch_cbet(f0, setup["gp"], fields=True, gain=tr.new_grid(per_beam=True))
     assert parity_err(f0.cpu().numpy().reshape(-1), f.reshape(-1)) < TOL
+    # the energy field alone (what every pass after the direction-building one deposits): component 0 of the above
+    for gain in (None, tr.new_grid(per_beam=True)):
+        fe = tr.new_fields()
+        tr.counters(reset=True)
+        tr.launch_cbet(fe[0], setup["gp"], fields="energy", gain=gain)
+        assert tr.counters(reset=True).ray_steps == c.ray_steps
+        fe = fe.cpu().numpy()
+        assert not fe[1:].any()
+        for b in range(len(BEAMS)):
+            assert parity_err(fe[0, b], setup["ofields"][0, b]) < TOL, b
 
 
 @pytest.mark.parametrize("symmetric", [False, True])
@@ -124,9 +134,17 @@ def test_gain_field_matches_oracle_and_is_antisymmetric(api, oracle, setup, torc
     assert np.abs(exch).max() <= 1e-11 * np.abs(inten * K).sum(axis=0).max()
     kmag = np.sqrt(nf[1] ** 2 + nf[2] ** 2 + nf[3] ** 2)
     present = setup["ofields"][0] > 0                 # where the beam deposited energy the entry is normalised
+    touched = setup["ofields"][0] != 0
     d = tr.derived
-    assert np.all(kmag[present] <= d.omega / 2.99792458e10 * (1 + 1e-12))
-    assert np.array_equal(nf[:, ~present], setup["ofields"][:, ~present])   # absent entries are left as deposited
+    assert np.all(kmag[touched] <= d.omega / 2.99792458e10 * (1 + 1e-12))
+    assert np.array_equal(nf[:, ~touched], setup["ofields"][:, ~touched])   # untouched entries are left alone
+    assert not nf[0][touched & ~present].any()                              # no intensity where the energy is not positive
+    # frozen directions: fresh energy on top of the k entries of that call gives the same K
+    fields[0] = torch_cuda.from_numpy(setup["ofields"][0].copy()).cuda()
+    gain_f = torch_cuda.zeros_like(gain)
+    tr.gain_field(fields, gain_f, gp, None, scratch=scratch, frozen=True)
+    assert np.abs(gain_f.cpu().numpy() - K).max() < 1e-12 * scale
+    assert np.array_equal(fields[1:].cpu().numpy(), nf[1:])                 # ... and leaves them alone
     # under-relaxation: a second call with relax = 0.25 moves a quarter of the way towards the same K
     gain2 = torch_cuda.zeros_like(gain)
     fields2 = torch_cuda.from_numpy(setup["ofields"].copy()).cuda()
@@ -153,11 +171,17 @@ def test_gain_pass_matches_oracle(api, oracle, setup, torch_cuda):
 def test_solve_converges_conserves_and_matches_oracle(api, oracle, setup, torch_cuda):
     tr, cfg, og = setup["tr"], setup["cfg"], setup["og"]
     gp = api.default_gain_params(tolerance=1e-6, max_passes=12, relax=1.0)   # six beams: plain iteration converges
-    # oracle: the same fixed-point iteration
-    K, passes = None, 0
+    # oracle: the same fixed-point iteration -- the direction fields of the gain-free first pass are kept
+    # (direction_passes = 1), later passes deposit the energy field only
+    assert gp.direction_passes == 1
+    K, passes, F = None, 0, None
     for it in range(gp.max_passes):
-        F = np.stack([oracle.trace_cbet(cfg, og, setup["bn"], setup["ne3d"], setup["kap"], gain=K, quantity=q,
-                                        per_beam=True, nthreads=NCPU)[0] for q in (1, 2, 3, 4)])
+        new = [oracle.trace_cbet(cfg, og, setup["bn"], setup["ne3d"], setup["kap"], gain=K, quantity=q,
+                                 per_beam=True, nthreads=NCPU)[0] for q in ((1, 2, 3, 4) if it == 0 else (1,))]
+        if it == 0:
+            F = np.stack(new)
+        else:
+            F[0] = new[0]
         K, ch = oracle.gain_field(cfg, og, F, setup["ne3d"], relax=gp.relax, gain=K, nthreads=NCPU)
         passes = it + 1
         if ch[0] / ch[1] < gp.tolerance:
@@ -194,7 +218,7 @@ def test_cbet_argument_errors(api, setup, torch_cuda):
     assert ei.value.code == api.EINVAL
     d = tr.derived
     stream = torch_cuda.cuda.current_stream().cuda_stream
-    with pytest.raises(api.CbetError) as ei:   # quantity is CBET_DEPOSIT_ENERGY or CBET_DEPOSIT_FIELDS
+    with pytest.raises(api.CbetError) as ei:   # quantity is CBET_DEPOSIT_ENERGY, _FIELDS or _FIELD_ENERGY
         api.trace_cbet(0, d.nindices, None, None, None, 5, e, None, tr.d_bbeam_norm, tr.d_beam_norm, tr.d_pow_r,
                        tr.d_phase_r, d.xconst, d.yconst, d.zconst, tr.params.copy(beam_lo=0, beam_hi=len(BEAMS)),
                        setup["gp"], tr.ctx, stream)
@@ -208,6 +232,9 @@ def test_cbet_argument_errors(api, setup, torch_cuda):
     with pytest.raises(api.CbetError) as ei:
         api.cbet_solve(tr.d_te, tr.d_r, tr.d_ne, e, tr.d_bbeam_norm, tr.d_beam_norm, tr.d_pow_r, tr.d_phase_r,
                        tr.params.copy(shard_index=0, shard_count=2), setup["gp"], ctx=tr.ctx)
+    assert ei.value.code == api.EINVAL
+    with pytest.raises(api.CbetError) as ei:   # at least one pass has to build the direction field
+        tr.launch_cbet(e, api.default_gain_params(direction_passes=0))
     assert ei.value.code == api.EINVAL
 
 
