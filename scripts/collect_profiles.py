@@ -1,0 +1,66 @@
+"""Condense what scripts/gpu_profile_round.sh left under gpurun_out/<tag>/ into profiles/<round>/ (the files the
+judge reads): bench lines, kernel stats, one small CSV per --pmc pass, the logs, and traffic.json -- the per-launch
+counts bench.py prices its roofline object with.  usage: python scripts/collect_profiles.py <gpurun_out/tag> <profiles/rN>"""
+import collections, csv, glob, json, os, shutil, sys
+
+src, dst = sys.argv[1], sys.argv[2]
+os.makedirs(os.path.join(dst, "pmc"), exist_ok=True)
+os.makedirs(os.path.join(dst, "cbet"), exist_ok=True)
+for f in ("bench_default.json", "bench_n100.json", "bench_n512.json", "bench_n512_rpz6.json", "kernel_stats.csv",
+          "shard_timing.log", "launch_size_curve.log"):
+    if os.path.exists(os.path.join(src, f)):
+        shutil.copy(os.path.join(src, f), os.path.join(dst, f))
+shutil.copy(os.path.join(src, "pmc", "summary.txt"), os.path.join(dst, "pmc", "summary.txt"))
+if os.path.exists(os.path.join(src, "cbet", "kernel_stats.csv")):
+    shutil.copy(os.path.join(src, "cbet", "kernel_stats.csv"), os.path.join(dst, "cbet", "kernel_stats.csv"))
+    with open(os.path.join(dst, "cbet", "cbet_profile.log"), "w") as fo:
+        for line in open(os.path.join(src, "cbet_profile.log")):
+            if not line[:5] in ("W2026", "E2026"):
+                fo.write(line)
+
+
+def short(k):
+    for name in ("k_trace_window", "k_step_table", "k_tabulate"):
+        if name in k:
+            return k[k.index(name):].split("(")[0] if name == "k_trace_window" else name
+    return None
+
+
+means = {}
+for p in range(1, 16):
+    files = glob.glob(os.path.join(src, "pmc", "p%d" % p, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        continue
+    vals = collections.OrderedDict()
+    for r in csv.DictReader(open(files[0])):
+        k = short(r["Kernel_Name"])
+        if k:
+            vals.setdefault((k, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
+    with open(os.path.join(dst, "pmc", "pass%d.csv" % p), "w") as fo:
+        w = csv.writer(fo)
+        w.writerow(["kernel", "counter", "dispatches", "mean", "min", "max"])
+        for (k, c), v in vals.items():
+            w.writerow([k, c, len(v), sum(v) / len(v), min(v), max(v)])
+            if k.startswith("k_trace_window"):
+                means[c] = (sum(v) / len(v), "pmc/pass%d.csv" % p)
+
+bench = json.load(open(os.path.join(dst, "bench_default.json")))
+rl = bench["roofline"]
+wave_steps = bench["config"]["ray_steps_per_pass"] / 64.0 / rl["lane_utilisation"]
+need = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "TCC_EA0_ATOMIC_sum", "FETCH_SIZE", "WRITE_SIZE")
+entry = {
+    "workload": bench["config"]["workload"], "kernel_variant": bench["config"]["kernel_variant"], "kernel": "k_trace_window",
+    "SQ_INSTS_VALU_per_launch": means["SQ_INSTS_VALU"][0], "SQ_INSTS_SALU_per_launch": means["SQ_INSTS_SALU"][0],
+    "SQ_INSTS_LDS_per_launch": means["SQ_INSTS_LDS"][0], "wave_steps_per_launch": wave_steps,
+    "TCC_EA0_ATOMIC_requests": means["TCC_EA0_ATOMIC_sum"][0],
+    "FETCH_SIZE_KiB": means["FETCH_SIZE"][0], "WRITE_SIZE_KiB": means["WRITE_SIZE"][0],
+    "hbm_bytes_per_launch": (means["FETCH_SIZE"][0] + means["WRITE_SIZE"][0]) * 1024.0,
+    "source": "%s: %s -- separate rocprofv3 --pmc passes of scripts/pmc.sh (no tracing flags beside them), mean of the "
+              "dispatches of the 256^3 pass; hbm = (FETCH_SIZE + WRITE_SIZE) * 1024 B.  FETCH_SIZE is uncalibrated for "
+              "gathers on gfx950 (MI355X_MICROARCH.md HBM section: it halves wide streaming reads); WRITE_SIZE checks out "
+              "on k_step_table in the same pass." % (dst, ", ".join("%s (%s)" % (means[c][1], c) for c in need)),
+}
+json.dump({"entries": [entry]}, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+print(json.dumps(entry, indent=1))
+print("per wave-step: VALU %.0f SALU %.0f LDS %.1f" % (entry["SQ_INSTS_VALU_per_launch"] / wave_steps,
+      entry["SQ_INSTS_SALU_per_launch"] / wave_steps, entry["SQ_INSTS_LDS_per_launch"] / wave_steps))
