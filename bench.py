@@ -150,6 +150,7 @@ def main():
     ap.add_argument("--n", "--grid", dest="n", type=int, default=256, help="grid nodes per axis (BASELINE config 3: 256)")
     ap.add_argument("--rays-per-zone", type=int, default=4, help="def.cuh:58 ships 4; BASELINE config 5 as stated (1.13e6 ray "
                     "ids per beam at 512^3) is 6")
+    ap.add_argument("--patch-order", type=int, default=None, help="cbet_params.patch_order (default: the library's)")
     ap.add_argument("--variant", type=int, default=0, help="cbet_params.kernel_variant (0 = default)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank flow on a 1-GPU box together with CBET_BENCH_DEVICE)")
@@ -181,7 +182,8 @@ def main():
     n = args.n
     r, ne, te = api.load_s83177()
     bn = api.omega60_beam_norm()
-    p = api.default_params(n, kernel_variant=args.variant, rays_per_zone=args.rays_per_zone)
+    p = api.default_params(n, kernel_variant=args.variant, rays_per_zone=args.rays_per_zone,
+                           **({} if args.patch_order is None else {"patch_order": args.patch_order}))
     workload = "omega60_%dcube_s83177_absorption" % n + ("" if args.rays_per_zone == 4 else "_rpz%d" % args.rays_per_zone)
     tr = RayTracer(p, r, ne, te, beam_norm=bn)
     d = tr.derived
@@ -193,6 +195,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    pipe.warm()            # N > 1: RCCL's communicator / channel set-up, outside every pass
     for _ in range(args.warmup):
         pipe.run_pass()
     fence()

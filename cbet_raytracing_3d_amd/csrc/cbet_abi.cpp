@@ -161,7 +161,8 @@ static void build_live_list(const cbet_params *p, const cbet_derived *d, int nin
                 const int cx = std::min(d->nrays_x - 1, x * 8 + 4), cy = std::min(d->nrays_y - 1, y * 8 + 4);
                 const double r2 = xl[cx] * xl[cx] + yl[cy] * yl[cy];
                 const double rmax2 = 2.0 * kBeamMax * kBeamMax * 1.1;
-                const unsigned long long ring = (unsigned long long)((1.0 - std::min(1.0, r2 / rmax2)) * 4095.0);  // 0 = outermost
+                const double levels = p->patch_order == 1 ? 4095.0 : (double)(p->patch_order - 1);   // >= 2: that many radial rings, Morton inside each
+                const unsigned long long ring = (unsigned long long)((1.0 - std::min(1.0, r2 / rmax2)) * levels);  // 0 = outermost
                 key |= ring << 32;
             }
             order.emplace_back(key, y * px + x);

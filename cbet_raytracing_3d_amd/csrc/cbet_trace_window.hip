@@ -429,6 +429,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
     bool inbox = false;                      // per lane: the deposit goes to LDS ...
     int tile_off = 0;                        // ... into this tile (offset in doubles)
     bool missed = false;                     // per lane: ... or straight to HBM
+    bool any_missed = false;                 // wave-uniform: some lane does
     int own_slot = 0, own_node = 0;          // CBET = 4: the ray's own node, in box A's component tiles / in the grid
     // The deposit of the step before (:341-348): a_c * increment to the eight nodes, a_c = (Fz * Fy) * Fx.
     auto deposit_previous = [&]() {
@@ -447,14 +448,16 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         for (int c = 0; c < 8; ++c) wgt[c] = wgt[c] * inc;   // a_c * increment
         if (inbox) {
             // slot = (x & XM) * XS + (y & YM) * YS + (z & ZM) with the masks and strides of the lane's tile
+            // (byte offsets throughout: a 24-bit multiply by the byte stride instead of multiply-then-shift)
             auto add8 = [&](int xm, int ym, int zm, int xs, int ys, int off) {
-                const int x0 = (X0 & xm) * xs + off, x1 = (X1 & xm) * xs + off;
-                const int y0 = (Y0 & ym) * ys, y1 = (Y1 & ym) * ys;
-                const int z0 = Z0 & zm, z1 = Z1 & zm;
+                const int x0 = __mul24(X0 & xm, xs * 8) + off * 8, x1 = __mul24(X1 & xm, xs * 8) + off * 8;
+                const int y0 = __mul24(Y0 & ym, ys * 8), y1 = __mul24(Y1 & ym, ys * 8);
+                const int z0 = (Z0 & zm) * 8, z1 = (Z1 & zm) * 8;
                 const int s00 = x0 + y0, s10 = x1 + y0, s01 = x0 + y1, s11 = x1 + y1;
-                auto add = [&](int slot, double w) {
-                    if (CBET_AUDIT(a, (unsigned)slot < (unsigned)NSLOT))
-                        __hip_atomic_fetch_add(&s_val[slot], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                auto add = [&](int byte, double w) {
+                    if (CBET_AUDIT(a, (unsigned)byte < (unsigned)NSLOT * 8u))
+                        __hip_atomic_fetch_add(static_cast<double *>(__builtin_assume_aligned(reinterpret_cast<char *>(s_val) + byte, 8)),
+                                               w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 };
                 add(s00 + z0, wgt[0]);
                 add(s10 + z0, wgt[1]);
@@ -474,8 +477,8 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
             }
         }
         // window misses: eight atomics, younger than the record gather just issued -- counted for its wait
-        wc.pend += (CBET_BALLOT(missed) != 0ull) ? 8 : 0;
-        if (missed) {
+        wc.pend += any_missed ? 8 : 0;
+        if (any_missed && missed) {
             const int nX0 = __mul24(X0, sXh), nX1 = __mul24(X1, sXh), nY0 = __mul24(Y0, sYh), nY1 = __mul24(Y1, sYh);
             global_add(a, &edep[nX0 + nY0 + Z0], wgt[0]);
             global_add(a, &edep[nX1 + nY0 + Z0], wgt[1]);
@@ -506,6 +509,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         }
         inbox = false;
         missed = false;
+        any_missed = false;
     };
 
     for (int tt = 0; tt < a.nt; ++tt) {                        // :207
@@ -685,9 +689,9 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
                     const bool useB = alive && homeB && inB;
                     inbox = useB || (alive && !homeB && inA);
                     tile_off = useB ? T::N : 0;
-                    const bool missed = CBET_BALLOT(alive && !inbox) != 0ull;
-                    if (missed) wc.steps_miss += 1u;
-                    deep = !missed && box_deep_inside<T>(oA, nx, ny, nz) && (!b_active || box_deep_inside<TB>(oB, nx, ny, nz));
+                    any_missed = CBET_BALLOT(alive && !inbox) != 0ull;
+                    if (any_missed) wc.steps_miss += 1u;
+                    deep = !any_missed && box_deep_inside<T>(oA, nx, ny, nz) && (!b_active || box_deep_inside<TB>(oB, nx, ny, nz));
                 }
             } else if (!deep) {
                 deep = box_deep_inside<T>(oA, nx, ny, nz) && (!b_active || box_deep_inside<TB>(oB, nx, ny, nz));

@@ -278,6 +278,17 @@ class SweepPipeline:
             self.work[b] = reduce_scatter_grid(self.grids[b], self.slabs[b], self.group, async_op=True)
         return b
 
+    def warm(self):
+        """Run the combine once on the (zero) buffers: RCCL builds its communicator, channels and staging buffers on
+        the first collective of a kind -- set-up, like the reference's cudaMalloc in its Init phase (main.cu:131-152),
+        not part of a pass.  No-op on one rank."""
+        if self.world > 1:
+            for b in range(2):
+                w = reduce_scatter_grid(self.grids[b], self.slabs[b], self.group, async_op=True)
+                if w is not None:
+                    w.wait()
+            torch.cuda.synchronize(self.tr.device)
+
     def finish(self):
         """Wait for everything in flight; returns the slab of the last pass (this rank's planes of the sum)."""
         for b in range(2):
