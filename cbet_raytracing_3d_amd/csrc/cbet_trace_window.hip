@@ -280,7 +280,9 @@ typedef double dbl2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void record_issue(const StepRecord *base, unsigned cell, dbl2 &kxy, dbl2 &kzk)
 {
     const char *p = reinterpret_cast<const char *>(base) + ((unsigned long long)cell << 5);
-    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"
+    // (the trailing comment names the destination registers in the assembly listing: tests/test_isa_audit.py checks
+    // that the wait below names the same ones, i.e. that the compiler never moved the in-flight record)
+    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16\n\t; CBET_RECORD_ISSUE %0 %1"
                  : "=&v"(kxy), "=&v"(kzk)
                  : "v"(p)
                  : "memory");
@@ -289,7 +291,8 @@ __device__ __forceinline__ void record_issue(const StepRecord *base, unsigned ce
 // pend = vector-memory instructions issued since record_issue (exact, or an underestimate -- never more)
 __device__ __forceinline__ void record_wait(dbl2 &kxy, dbl2 &kzk, int pend)
 {
-    asm volatile("s_cmp_eq_u32 %2, 0\n\t"
+    asm volatile("; CBET_RECORD_WAIT %0 %1\n\t"
+                 "s_cmp_eq_u32 %2, 0\n\t"
                  "s_cbranch_scc0 .Lrw_nz_%=\n\t"
                  "s_waitcnt vmcnt(0)\n\t"
                  "s_branch .Lrw_end_%=\n"
