@@ -86,7 +86,7 @@ def cbet_leg(api, tr, edep, n):
 
 def measured_traffic(workload, variant):
     """Per-launch counter values of the trace kernel from the committed PMC passes (profiles/r*/traffic.json:
-    SQ_INSTS_VALU, TCC_EA0_ATOMIC, (FETCH_SIZE + WRITE_SIZE) * 1 KiB, each collected in its own --pmc pass); the
+    SQ_INSTS_VALU, TCC_EA0_ATOMIC, (2 x FETCH_SIZE + WRITE_SIZE) * 1 KiB, each collected in its own --pmc pass); the
     newest round's entry for this workload and the shipped kernel wins.  None when there is none."""
     best = None
     prof = os.path.join(ROOT, "profiles")
@@ -135,7 +135,7 @@ def roofline(prof, steps_per_launch, kernel_s, tot, steps_total):
         "secondary": {"bound": "memory_side_atomics", "achieved": atom / 1e9, "peak": ATOMIC_PEAK / 1e9, "unit": "GB/s",
                       "frac": atom / ATOMIC_PEAK, "requests_per_launch": prof["TCC_EA0_ATOMIC_requests"]},
         "formula": "frac = SQ_INSTS_VALU / kernel_s / (1024 SIMDs x 2.4 GHz / 4); secondary.frac = TCC_EA0_ATOMIC x 64 B / "
-                   "kernel_s / 1.3 TB/s; hbm_measured_frac = (FETCH_SIZE + WRITE_SIZE) x 1 KiB / kernel_s / 8 TB/s",
+                   "kernel_s / 1.3 TB/s; hbm_measured_frac = (2 x FETCH_SIZE + WRITE_SIZE) x 1 KiB / kernel_s / 8 TB/s (FETCH_SIZE tallies 128-B line requests at 64 B on gfx950: calibrated, profiles/r2/fetch_calibration.log)",
         "note": "bound = vector-instruction issue (PMC: VALU busy the largest share of SIMD cycles); the algorithmic "
                 "128 B/ray-step figure is kept as algorithmic_GBps for context -- it exceeds the HBM peak because gathers "
                 "hit L2/MALL and scatters are combined in LDS (DESIGN.md 4.3)"})

@@ -54,11 +54,14 @@ entry = {
     "SQ_INSTS_LDS_per_launch": means["SQ_INSTS_LDS"][0], "wave_steps_per_launch": wave_steps,
     "TCC_EA0_ATOMIC_requests": means["TCC_EA0_ATOMIC_sum"][0],
     "FETCH_SIZE_KiB": means["FETCH_SIZE"][0], "WRITE_SIZE_KiB": means["WRITE_SIZE"][0],
-    "hbm_bytes_per_launch": (means["FETCH_SIZE"][0] + means["WRITE_SIZE"][0]) * 1024.0,
+    # FETCH_SIZE = TCC_EA0_RDREQ x 64 B, but every request moves a 128-B line: calibrated on 32-byte record gathers
+    # of a known 1 GiB (scripts/ubench/fetch_calib.hip, profiles/r2/fetch_calibration.log) -> x 2
+    "hbm_bytes_per_launch": (2.0 * means["FETCH_SIZE"][0] + means["WRITE_SIZE"][0]) * 1024.0,
     "source": "%s: %s -- separate rocprofv3 --pmc passes of scripts/pmc.sh (no tracing flags beside them), mean of the "
-              "dispatches of the 256^3 pass; hbm = (FETCH_SIZE + WRITE_SIZE) * 1024 B.  FETCH_SIZE is uncalibrated for "
-              "gathers on gfx950 (MI355X_MICROARCH.md HBM section: it halves wide streaming reads); WRITE_SIZE checks out "
-              "on k_step_table in the same pass." % (dst, ", ".join("%s (%s)" % (means[c][1], c) for c in need)),
+              "dispatches of the 256^3 pass; hbm = (2 x FETCH_SIZE + WRITE_SIZE) * 1024 B: on gfx950 FETCH_SIZE tallies 128-B "
+              "line requests at 64 B (MI355X_MICROARCH.md HBM section), calibrated for this kernel's 32-byte record gathers on "
+              "a known 1 GiB with scripts/ubench/fetch_calib.hip (profiles/r2/fetch_calibration.log: exactly half of the bytes "
+              "moved in every pattern); WRITE_SIZE checks out on k_step_table in the same pass (+3 %%)." % (dst, ", ".join("%s (%s)" % (means[c][1], c) for c in need)),
 }
 json.dump({"entries": [entry]}, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 print(json.dumps(entry, indent=1))
