@@ -1,0 +1,63 @@
+"""CPU, oracle ray paths: for a few bundles of the 256^3 sweep, the LDS address pattern of every deposit instruction
+(ds_add_f64 of one corner for 64 lanes) under the shipped corner order and tile layout -- how many lanes hit the same
+address, how many distinct addresses share the busiest bank.  Result: 63 lanes -> 32 distinct
+addresses, busiest address hit by 5.6 lanes on average: the four cells of a bundle share their central nodes, which
+therefore receive a quarter of all adds; no corner order can spread 64 adds per wave-step over fewer than 8 per
+instruction there.  usage: python scripts/lds_pattern.py"""
+import sys, numpy as np
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import load_inputs
+from oracle import cbet_oracle as O
+from cbet_raytracing_3d_amd import api
+n = 256
+bn, r, ne, te = load_inputs()
+cfg = O.default_config(n)
+p = api.default_params(n)
+live = api.live_ray_list(p)
+d = O.derive(cfg)
+XS, YS = 140, 17
+def analyse(beam, patch, banks=32):
+    ids = live[64 * patch: 64 * patch + 64]
+    paths = {}
+    for lane, rid in enumerate(ids):
+        if rid >= 0:
+            pt = O.ray_path(cfg, bn, r, ne, te, beam, int(rid))
+            if len(pt): paths[lane] = pt
+    T = max(len(v) for v in paths.values())
+    out = []
+    for t in range(0, T):
+        lanes = [l for l, v in paths.items() if len(v) > t]
+        if len(lanes) < 8: continue
+        # path row: x,y,z,... need cell + offsets: recompute from position
+        rows = np.array([paths[l][t] for l in lanes])
+        pos = rows[:, 0:3]
+        f = (pos - np.array([cfg.xmin, cfg.ymin, cfg.zmin])) / np.array([d.dx, d.dy, d.dz])
+        c = rows[:, 3:6].astype(int)
+        off = f - c                          # in (-0.5, 0.5]
+        low = c + 1 - (off - 0.5 < 0)        # haloed low corner: own node (haloed c+1) minus one iff negative... (off-0.5 always < 0)
+        low = c                               # all-negative path: low corner haloed = c (own haloed = c+1)
+        L = np.array(lanes)
+        flx, fly, flz = (L & 1), (L >> 1) & 1, (L >> 3) & 1
+        # first-visited node per axis: own (= low+1) unless flipped
+        X0 = low[:, 0] + (1 - flx); X1 = low[:, 0] + flx
+        Y0 = low[:, 1] + (1 - fly); Y1 = low[:, 1] + fly
+        Z0 = low[:, 2] + (1 - flz); Z1 = low[:, 2] + flz
+        seq = [(X0, Y0, Z0), (X1, Y0, Z0), (X0, Y0, Z1), (X1, Y0, Z1), (X0, Y1, Z0), (X1, Y1, Z0), (X0, Y1, Z1), (X1, Y1, Z1)]
+        for (X, Y, Z) in seq:
+            slot = (X & 7) * XS + (Y & 7) * YS + (Z & 15)
+            uniq, cnt = np.unique(slot, return_counts=True)
+            bank = uniq % banks
+            bl = np.bincount(bank, minlength=banks)
+            out.append((len(lanes), len(uniq), cnt.max(), bl.max()))
+    return np.array(out)
+res = []
+for beam, patch in ((0, 300), (0, 700), (0, 1100), (7, 500), (23, 1200), (41, 900), (30, 1500)):
+    a = analyse(beam, patch)
+    if a.ndim != 2: continue
+    res.append(a)
+    print("beam %d patch %d: instrs %d  lanes %.1f  distinct addresses %.1f  max same-address %.2f  max distinct-per-bank %.2f" %
+          (beam, patch, len(a), a[:, 0].mean(), a[:, 1].mean(), a[:, 2].mean(), a[:, 3].mean()))
+a = np.concatenate(res)
+print("all: lanes %.1f distinct %.1f max same-address %.2f (hist %s) max per bank %.2f (hist %s)" % (a[:,0].mean(), a[:,1].mean(), a[:,2].mean(), np.bincount(a[:,2])[:10], a[:,3].mean(), np.bincount(a[:,3])[:8]))
