@@ -78,23 +78,33 @@ for case in range(max(4, cases // 5)):
     bg = torch.zeros(nb, dtype=torch.float64, device="cuda")
     tr.launch_cbet(f, gp, fields=True, gain=d_gain)
     tr.launch_cbet(e, gp, gain=d_gain, beam_gain=bg)
+    fe = tr.new_fields()
+    tr.launch_cbet(fe[0], gp, fields="energy", gain=d_gain)     # the energy field alone, z-brick kernel
     of = np.stack([O.trace_cbet(cfg, og, bn[beams].copy(), ne3d, kap, gain=gain, quantity=q, per_beam=True, nthreads=8)[0]
                    for q in (1, 2, 3, 4)])
     oe, osteps, obg = O.trace_cbet(cfg, og, bn[beams].copy(), ne3d, kap, gain=gain, nthreads=8)
     errs = [float(np.abs(f.cpu().numpy() - of).max() / max(np.abs(of).max(), 1e-300)),
+            float(np.abs(fe[0].cpu().numpy() - of[0]).max() / max(np.abs(of[0]).max(), 1e-300)),
             parity_err(e.cpu().numpy(), oe) if np.abs(oe).max() > 0 else 0.0,
             float(np.abs(bg.cpu().numpy() - obg).max() / max(np.abs(obg).max(), 1e-300))]
     K = {}
     for sym in (False, True):      # both gain kernels on the oracle's fields
         g2 = tr.new_grid(per_beam=True)
-        tr.gain_field(torch.from_numpy(of.copy()).cuda(), g2, gp, None, scratch=torch.empty_like(g2) if sym else None)
+        df = torch.from_numpy(of.copy()).cuda()
+        tr.gain_field(df, g2, gp, None, scratch=torch.empty_like(g2) if sym else None)
         K[sym] = g2.cpu().numpy()
+        # ... and again with fresh energy on top of the direction entries that call left (frozen directions)
+        df[0] = torch.from_numpy(of[0].copy()).cuda()
+        g3 = tr.new_grid(per_beam=True)
+        tr.gain_field(df, g3, gp, None, scratch=torch.empty_like(g3) if sym else None, frozen=True)
+        K[(sym, "frozen")] = g3.cpu().numpy()
     ok_, _ = O.gain_field(cfg, og, of, ne3d, relax=1.0, nthreads=8)
     scale = max(np.abs(ok_).max(), 1e-300)
-    errs += [float(np.abs(K[False] - ok_).max() / scale), float(np.abs(K[True] - ok_).max() / scale)]
+    errs += [float(np.abs(K[False] - ok_).max() / scale), float(np.abs(K[True] - ok_).max() / scale),
+             float(np.abs(K[(False, "frozen")] - ok_).max() / scale), float(np.abs(K[(True, "frozen")] - ok_).max() / scale)]
     ok = max(errs) < 1e-9
     worst = max(worst, max(errs)); bad += not ok
-    print("cbet case %2d %s grid %s beams %d rpz %d: fields %.1e edep %.1e beam-gain %.1e K %.1e K(sym) %.1e (max |K| %.3g)" %
+    print("cbet case %2d %s grid %s beams %d rpz %d: fields %.1e energy field %.1e edep %.1e beam-gain %.1e K %.1e K(sym) %.1e frozen %.1e %.1e (max |K| %.3g)" %
           ((case, "ok  " if ok else "FAIL", (nx, ny, nz), nb, rpz) + tuple(errs) + (float(np.abs(ok_).max()),)), flush=True)
     tr.close()
 print("cases %d, failures %d, worst err %.2e" % (cases, bad, worst))
