@@ -10,13 +10,14 @@
 //                      tables in HBM, ne3d and kappa3d (= ed/ncrit*nuei*dt, launch_ray_XZ.cu:296-305
 //                      without the trailing *uray).  The reference re-interpolates the profile eight
 //                      times per ray-step (8 bisections + 9 sqrt + 9 div); with the tables a ray-step is
-//                      seven 8-byte gathers and ~60 flops, no sqrt/div.
+//                      seven 8-byte gathers and ~60 flops, no sqrt/div (k_trace_simple) -- or, folded once
+//                      more into one 32-byte record per node by k_step_table, a single gather (the shipped kernel).
 //   * k_trace_simple : one wavefront = one 8x8-ray patch, the reference's step loop written plainly
 //                      (literal relocation loop, no software pipeline), with the deposit either as
 //       1  GLOBAL : 8 global_atomic_add_f64 per ray-step -- the reference's own scheme, the baseline; or
 //       2  TAGGED : a wave-private toroidal LDS tile with node tags; slots are claimed by LDS CAS and
 //                   written back with one global atomic when another node claims them.
-//     Both exist to cross-check the shipped kernel (tests/) and to price its deposit scheme (DESIGN.md 4.2).
+//     Both exist to cross-check the shipped kernel (tests/) and to price its deposit scheme (DESIGN.md 4.6).
 #include <hip/hip_runtime.h>
 
 #include "cbet_trace_common.h"

@@ -5,9 +5,10 @@
 // (/root/reference/launch_ray_XZ.cu:207-357; the file is built with -ffp-contract=off); what is
 // MI355X-specific is everything around it:
 //
-//   * plasma: node tables ne3d / kappa3d in HBM (k_tabulate), gathered by 32-bit byte offsets from a
-//     uniform base; the seven gathers of a step are issued as soon as the ray's new cell is known and
-//     are consumed one step later (software pipeline).
+//   * plasma: one 32-byte record per node (k_step_table: the three kicks with the reference's edge rule baked in,
+//     and the absorption coefficient), gathered once per step from inline assembly and waited for with a counted
+//     vmcnt (record_issue / record_wait); the loop is rotated so that the previous step's deposit, this step's
+//     weights and the window logic all run between a gather and its wait.
 //   * relocation: for cells deep inside the grid the reference's mutating-bound candidate loop
 //     (:282-292) is a function of g = f - cell alone and every difference it forms is exact, so it is
 //     evaluated with two comparisons (cbet_relocate.h, relocate_deep_interior; fuzzed against the
@@ -25,8 +26,8 @@
 // Template parameters: WZ = z extent of a tile (16: aligned z-bricks; 8: single z-planes, used by the
 // CBET field pass whose three extra component tiles would not fit otherwise); GENERIC = run-time
 // absorption flag and 64-bit table indexing (grids of >= 2^32 table bytes, bookkeeping mode) instead
-// of the compiled-in common case; CBET = 0 none, 1 gain hooks, 2 gain hooks + the energy field deposited, 4 fused four-component field pass
-// (no reference counterpart: DESIGN.md section 9).
+// of the compiled-in common case; CBET = 0 none, 1 gain hooks, 2 gain hooks + the energy field deposited,
+// 4 fused four-component field pass (no reference counterpart: DESIGN.md section 9).
 #include <hip/hip_runtime.h>
 
 #include "cbet_trace_common.h"
@@ -391,10 +392,9 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
     // wave-uniform: every live lane was held by a box after the last step and both boxes lie deep inside the grid
     bool deep = false;
 
-    // Software pipeline: a step's record (cbet_device.h StepRecord: the three kicks and the absorption coefficient
-    // at the ray's node) is gathered as soon as the new node is known; the absorption coefficient is used by the
-    // same step's deposit, the kicks by the NEXT step's move -- so the gather is in flight during the whole
-    // deposit phase.  One aligned 32-byte gather per lane and step.
+    // A step's record (cbet_device.h StepRecord: the three kicks and the absorption coefficient at the ray's node) is
+    // gathered as soon as the new node is known; the absorption coefficient is used at the end of the same step,
+    // the kicks by the NEXT step's move.  One aligned 32-byte gather per lane and step.
     dbl2 rec_kxy, rec_kzk;                   // {kx, ky}, {kz, kappa} of the ray's node
     auto gather_record = [&]() {             // all lanes (a dead lane reads node 0); see record_issue
         unsigned c = alive ? cell : 0u;
