@@ -26,6 +26,7 @@ HBM_PEAK = 8.0e12             # MI355X_MICROARCH.md: HBM3E spec B/s (6.29e12 mea
 SIMDS, CLOCK_HZ = 1024, 2.4e9 # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, max clock
 VALU_ISSUE_PEAK = SIMDS * CLOCK_HZ / 4.0     # one wave-instruction per SIMD per 4 cycles ("vector-instruction ISSUE cost")
 ATOMIC_PEAK = 1.3e12          # MI355X_MICROARCH.md "Global float atomics": bytes/s of 64-B memory-side atomic requests
+LDS_CYCLE_PEAK = 256 * CLOCK_HZ  # one LDS array per CU: CU-cycles per second the LDS could be busy
 
 
 COMBINE_NOTE = ("two passes in flight per rank on three HIP streams (prepare tables | trace | RCCL reduce-scatter of the "
@@ -134,6 +135,11 @@ def roofline(prof, steps_per_launch, kernel_s, tot, steps_total):
         "hbm_measured_GBps": hbm / 1e9, "hbm_peak_GBps": HBM_PEAK / 1e9, "hbm_measured_frac": hbm / HBM_PEAK,
         "secondary": {"bound": "memory_side_atomics", "achieved": atom / 1e9, "peak": ATOMIC_PEAK / 1e9, "unit": "GB/s",
                       "frac": atom / ATOMIC_PEAK, "requests_per_launch": prof["TCC_EA0_ATOMIC_requests"]},
+        # the other unit at the same level of use: the per-CU LDS arrays (fp64 atomic adds of the deposit windows)
+        "lds": ({"bound": "lds_array_cycles", "achieved": prof["SQ_LDS_IDX_ACTIVE_per_launch"] / kernel_s / 1e9,
+                 "peak": LDS_CYCLE_PEAK / 1e9, "unit": "G CU-cycles/s",
+                 "frac": prof["SQ_LDS_IDX_ACTIVE_per_launch"] / kernel_s / LDS_CYCLE_PEAK}
+                if "SQ_LDS_IDX_ACTIVE_per_launch" in prof else None),
         "formula": "frac = SQ_INSTS_VALU / kernel_s / (1024 SIMDs x 2.4 GHz / 4); secondary.frac = TCC_EA0_ATOMIC x 64 B / "
                    "kernel_s / 1.3 TB/s; hbm_measured_frac = (2 x FETCH_SIZE + WRITE_SIZE) x 1 KiB / kernel_s / 8 TB/s (FETCH_SIZE tallies 128-B line requests at 64 B on gfx950: calibrated, profiles/r2/fetch_calibration.log)",
         "note": "bound = vector-instruction issue (PMC: VALU busy the largest share of SIMD cycles); the algorithmic "

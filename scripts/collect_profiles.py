@@ -47,11 +47,12 @@ for p in range(1, 16):
 bench = json.load(open(os.path.join(dst, "bench_default.json")))
 rl = bench["roofline"]
 wave_steps = bench["config"]["ray_steps_per_pass"] / 64.0 / rl["lane_utilisation"]
-need = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "TCC_EA0_ATOMIC_sum", "FETCH_SIZE", "WRITE_SIZE")
+need = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE", "TCC_EA0_ATOMIC_sum", "FETCH_SIZE", "WRITE_SIZE")
 entry = {
     "workload": bench["config"]["workload"], "kernel_variant": bench["config"]["kernel_variant"], "kernel": "k_trace_window",
     "SQ_INSTS_VALU_per_launch": means["SQ_INSTS_VALU"][0], "SQ_INSTS_SALU_per_launch": means["SQ_INSTS_SALU"][0],
     "SQ_INSTS_LDS_per_launch": means["SQ_INSTS_LDS"][0], "wave_steps_per_launch": wave_steps,
+    "SQ_LDS_IDX_ACTIVE_per_launch": means["SQ_LDS_IDX_ACTIVE"][0],   # cycles the LDS arrays were busy, summed over the CUs
     "TCC_EA0_ATOMIC_requests": means["TCC_EA0_ATOMIC_sum"][0],
     "FETCH_SIZE_KiB": means["FETCH_SIZE"][0], "WRITE_SIZE_KiB": means["WRITE_SIZE"][0],
     # FETCH_SIZE = TCC_EA0_RDREQ x 64 B, but every request moves a 128-B line: calibrated on 32-byte record gathers
