@@ -390,6 +390,26 @@ def test_trace_with_caller_supplied_node_tables(api, oracle, inputs, torch_cuda)
     tr.close()
 
 
+def test_patch_orders_trace_the_same_rays(api, inputs, oracle, torch_cuda):
+    """cbet_params.patch_order only changes which bundle a workgroup takes: Morton (0), longest first (1), k radial
+    rings with Morton inside (k >= 2) -- every order lists every live ray once and deposits the oracle's grid."""
+    bn, r, ne, te = inputs
+    cfg = oracle.default_config(40, nbeams=3)
+    want, steps = oracle.trace(cfg, bn[[0, 17, 42]], r, ne, te, nthreads=NCPU)
+    lists = []
+    for order in (0, 1, 2, 5, 64):
+        tr = make_tracer(api, inputs, 40, beams=[0, 17, 42], patch_order=order)
+        live = api.live_ray_list(tr.params)
+        lists.append(np.sort(live[live >= 0]))
+        assert len(live) % 64 == 0
+        e, c = run(tr, torch_cuda)
+        assert c.ray_steps == steps, order
+        assert parity_err(e, want) < PARITY_TOL, order
+        tr.close()
+    for l in lists[1:]:
+        assert np.array_equal(l, lists[0])
+
+
 def test_window_kernel_combines_and_is_parity_exact(api, oracle, inputs, torch_cuda):
     """The LDS windows only reorder fp64 sums: same grid and step count as the oracle on a beam subset whose
     bundles fan out in every direction, with most deposits combined in LDS before they reach HBM."""
