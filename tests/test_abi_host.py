@@ -157,6 +157,13 @@ def test_error_paths_without_a_gpu(api):
     with pytest.raises(api.CbetError) as ei:
         api.derive(p.copy(nx=1400, ny=1400, nz=1400))   # (n+2)^3 >= 2^31: 32-bit node tags
     assert ei.value.code == api.EINVAL
+    # thin anisotropic grids: the kernels form cell and node indices with 24-bit multiplies, so nx*ny and
+    # (ny+2)(nz+2) must stay below 2^23 even when the whole grid is far below 2^31 nodes
+    for shape in (dict(nx=4000, ny=4000, nz=3), dict(nx=200, ny=3000, nz=3000), dict(nx=3, ny=2900, nz=2900)):
+        with pytest.raises(api.CbetError) as ei:
+            api.derive(p.copy(**shape))
+        assert ei.value.code == api.EINVAL and "anisotropic" in str(ei.value)
+    api.derive(p.copy(nx=2800, ny=2900, nz=3))         # 8.1e6 < 2^23 = 8.4e6: accepted
     with pytest.raises(api.CbetError) as ei:           # multi_gpu.cpp:45-48
         api.moveToAndFromGPU(np.zeros(4), np.zeros(4), 32, -1)
     assert ei.value.code == api.ENODEVICE
