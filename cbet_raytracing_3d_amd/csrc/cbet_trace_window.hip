@@ -30,6 +30,8 @@
 // 4 fused four-component field pass (no reference counterpart: DESIGN.md section 9).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "cbet_trace_common.h"
 
 namespace cbet {
@@ -80,6 +82,49 @@ struct WaveCounters {
 // lanes, so one wave instruction covers whole rows -- 64-B lines when the z origin is brick-aligned.  Every vector
 // memory instruction that is really issued (some lane has a non-zero sum) is counted in wc.pend: the step's wait
 // for its record gather skips exactly that many younger instructions (see the kernel).
+template <class T, int AX, int NC>
+__device__ __forceinline__ void retire_plane(const TraceArgs &a, double *tile, const Origin &o, int coord, int lane,
+                                             double *edep, int sXh, int sYh, WaveCounters &wc, int coff, long gstride);
+
+// Two neighbouring planes (coord and coord2) of a single-component tile at once: all reads first, one wait.
+template <class T, int AX>
+__device__ __forceinline__ void retire_two_planes(const TraceArgs &a, double *tile, const Origin &o, int coord, int coord2,
+                                                  int lane, double *edep, int sXh, int sYh, WaveCounters &wc)
+{
+    constexpr int WO = AX == 0 ? T::WY : T::WX;
+    constexpr int IT = (WO * T::WZ + kWave - 1) / kWave;
+    double v[2 * IT];
+    int slot[2 * IT], node[2 * IT];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+        const int c = pl == 0 ? coord : coord2;
+        const int fixed = c & (AX == 0 ? T::XM : T::YM);
+#pragma unroll
+        for (int e = 0; e < IT; ++e) {
+            const int idx = e * kWave + lane, r0 = idx / T::WZ, r1 = idx & T::ZM, k = abs_in<T::ZM>(o.z, r1);
+            const int q = pl * IT + e;
+            if (AX == 0) {
+                slot[q] = fixed * T::XS + r0 * T::YS + r1;
+                node[q] = c * sXh + abs_in<T::YM>(o.y, r0) * sYh + k;
+            } else {
+                slot[q] = r0 * T::XS + fixed * T::YS + r1;
+                node[q] = abs_in<T::XM>(o.x, r0) * sXh + c * sYh + k;
+            }
+            const bool ok = (!(WO * T::WZ < kWave) || idx < WO * T::WZ) && CBET_AUDIT(a, (unsigned)slot[q] < (unsigned)T::N);
+            v[q] = ok ? tile[slot[q]] : 0.0;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 2 * IT; ++q) {
+        wc.pend += (CBET_BALLOT(v[q] != 0.0) != 0ull) ? 1 : 0;
+        if (v[q] != 0.0) {
+            tile[slot[q]] = 0.0;
+            ++wc.n_atomics;
+            global_add(a, &edep[node[q]], v[q]);
+        }
+    }
+}
+
 template <class T, int AX, int NC>
 __device__ __forceinline__ void retire_plane(const TraceArgs &a, double *tile, const Origin &o, int coord, int lane,
                                              double *edep, int sXh, int sYh, WaveCounters &wc, int coff, long gstride)
@@ -192,10 +237,13 @@ __device__ __forceinline__ void flush_box(const TraceArgs &a, double *tile, cons
         retire_plane<T, 0, NC>(a, tile, o, o.x + t, lane, edep, sXh, sYh, wc, coff, gstride);
 }
 
-// Wave-uniform decision of the hysteresis rule for one axis followed by single planes: -1 / +1 = shift the
-// origin down / up, 0 = stay.  r = the lane's low-corner offset from the origin, mm = ballot of the box's member
-// lanes, S = the largest offset at which a lane's two nodes still lie inside.  Shift when a member sits on an
-// edge cell or outside, never shift a member out, never shift back on the next step.
+// Wave-uniform decision of the hysteresis rule for one axis followed by planes: the number of planes to shift the
+// origin by, negative = down, 0 = stay.  r = the lane's low-corner offset from the origin, mm = ballot of the box's
+// member lanes, S = the largest offset at which a lane's two nodes still lie inside.  Shift when a member sits on
+// an edge cell or outside, never shift a member out, never shift back on the next step.  Boxes at least 8 wide
+// shift by TWO planes when every member would still sit a plane clear of the far edge afterwards: a bundle that
+// advances along the axis then shifts every other cell (0.26 instead of 0.39 shifts per wave-step at 256^3), and a
+// shift costs mostly its fixed part -- the decisions and a round trip through the LDS queue.
 __device__ __forceinline__ int follow_plane_axis(int r, unsigned long long mm, int S)
 {
     if ((__builtin_amdgcn_ballot_w64((unsigned)(r - 1) >= (unsigned)(S - 1)) & mm) == 0ull) return 0;
@@ -204,7 +252,13 @@ __device__ __forceinline__ int follow_plane_axis(int r, unsigned long long mm, i
     const bool above = (__builtin_amdgcn_ballot_w64(r > S) & mm) != 0ull, at_hi = (__builtin_amdgcn_ballot_w64(r >= S) & mm) != 0ull,
                near_hi = (__builtin_amdgcn_ballot_w64(r >= S - 1) & mm) != 0ull;
     const bool want_down = below || (at_lo && !near_hi), want_up = above || (at_hi && !near_lo);
-    return (want_down && !at_hi) ? -1 : ((want_up && !at_lo) ? 1 : 0);
+    int d = (want_down && !at_hi) ? -1 : ((want_up && !at_lo) ? 1 : 0);
+    if (S >= 6 && d != 0) {
+        const bool far_lo = (__builtin_amdgcn_ballot_w64(r <= 2) & mm) != 0ull, far_hi = (__builtin_amdgcn_ballot_w64(r >= S - 2) & mm) != 0ull;
+        if (d == 1 && !far_lo) d = 2;
+        if (d == -1 && !far_hi) d = -2;
+    }
+    return d;
 }
 
 // ... and for z followed by aligned bricks (WZ = 16): the lane's two z nodes are r, r + 1 in [0, 16); shift by a
@@ -226,13 +280,25 @@ __device__ __forceinline__ bool follow_box(const TraceArgs &a, double *tile, Ori
                                            int ly, int lz, int lane, double *edep, int sXh, int sYh, WaveCounters &wc,
                                            int coff, long gstride)
 {
+    auto leave = [&](auto axis, int d, int lo, int hi) {   // planes [lo, lo + |d|) or (hi - |d|, hi] leave along this axis
+        constexpr int AX = decltype(axis)::value;
+        const int first = d < 0 ? hi : lo, second = d < 0 ? hi - 1 : lo + 1;
+        if (d == 2 || d == -2) {
+            if constexpr (NC == 1) {
+                retire_two_planes<T, AX>(a, tile, o, first, second, lane, edep, sXh, sYh, wc);
+            } else {
+                retire_plane<T, AX, NC>(a, tile, o, first, lane, edep, sXh, sYh, wc, coff, gstride);
+                retire_plane<T, AX, NC>(a, tile, o, second, lane, edep, sXh, sYh, wc, coff, gstride);
+            }
+        } else {
+            retire_plane<T, AX, NC>(a, tile, o, first, lane, edep, sXh, sYh, wc, coff, gstride);
+        }
+    };
     const int dx = follow_plane_axis(lx - o.x, mm, T::SX);
-    if (dx != 0)
-        retire_plane<T, 0, NC>(a, tile, o, dx < 0 ? o.x + T::WX - 1 : o.x, lane, edep, sXh, sYh, wc, coff, gstride);
+    if (dx != 0) leave(std::integral_constant<int, 0>{}, dx, o.x, o.x + T::WX - 1);
     o.x += dx;
     const int dy = follow_plane_axis(ly - o.y, mm, T::SY);
-    if (dy != 0)
-        retire_plane<T, 1, NC>(a, tile, o, dy < 0 ? o.y + T::WY - 1 : o.y, lane, edep, sXh, sYh, wc, coff, gstride);
+    if (dy != 0) leave(std::integral_constant<int, 1>{}, dy, o.y, o.y + T::WY - 1);
     o.y += dy;
     int dz;
     if constexpr (T::BRICK) {
@@ -242,6 +308,8 @@ __device__ __forceinline__ bool follow_box(const TraceArgs &a, double *tile, Ori
         dz = follow_plane_axis(lz - o.z, mm, T::SZ);
         if (dz != 0)
             retire_zplane<T, NC>(a, tile, o, dz < 0 ? o.z + T::WZ - 1 : o.z, lane, edep, sXh, sYh, wc, coff, gstride);
+        if (dz == 2 || dz == -2)
+            retire_zplane<T, NC>(a, tile, o, dz < 0 ? o.z + T::WZ - 2 : o.z + 1, lane, edep, sXh, sYh, wc, coff, gstride);
     }
     o.z += dz;
     const bool moved = (dx | dy | dz) != 0;
