@@ -86,18 +86,18 @@ template <class T, int AX, int NC>
 __device__ __forceinline__ void retire_plane(const TraceArgs &a, double *tile, const Origin &o, int coord, int lane,
                                              double *edep, int sXh, int sYh, WaveCounters &wc, int coff, long gstride);
 
-// Two neighbouring planes (coord and coord2) of a single-component tile at once: all reads first, one wait.
-template <class T, int AX>
-__device__ __forceinline__ void retire_two_planes(const TraceArgs &a, double *tile, const Origin &o, int coord, int coord2,
-                                                  int lane, double *edep, int sXh, int sYh, WaveCounters &wc)
+// COUNT neighbouring planes (coord, coord + step, ...) of a single-component tile at once: all reads first, one wait.
+template <class T, int AX, int COUNT>
+__device__ __forceinline__ void retire_planes(const TraceArgs &a, double *tile, const Origin &o, int coord, int step,
+                                              int lane, double *edep, int sXh, int sYh, WaveCounters &wc)
 {
     constexpr int WO = AX == 0 ? T::WY : T::WX;
     constexpr int IT = (WO * T::WZ + kWave - 1) / kWave;
-    double v[2 * IT];
-    int slot[2 * IT], node[2 * IT];
+    double v[COUNT * IT];
+    int slot[COUNT * IT], node[COUNT * IT];
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl) {
-        const int c = pl == 0 ? coord : coord2;
+    for (int pl = 0; pl < COUNT; ++pl) {
+        const int c = coord + pl * step;
         const int fixed = c & (AX == 0 ? T::XM : T::YM);
 #pragma unroll
         for (int e = 0; e < IT; ++e) {
@@ -115,7 +115,7 @@ __device__ __forceinline__ void retire_two_planes(const TraceArgs &a, double *ti
         }
     }
 #pragma unroll
-    for (int q = 0; q < 2 * IT; ++q) {
+    for (int q = 0; q < COUNT * IT; ++q) {
         wc.pend += (CBET_BALLOT(v[q] != 0.0) != 0ull) ? 1 : 0;
         if (v[q] != 0.0) {
             tile[slot[q]] = 0.0;
@@ -254,9 +254,9 @@ __device__ __forceinline__ int follow_plane_axis(int r, unsigned long long mm, i
     const bool want_down = below || (at_lo && !near_hi), want_up = above || (at_hi && !near_lo);
     int d = (want_down && !at_hi) ? -1 : ((want_up && !at_lo) ? 1 : 0);
     if (S >= 6 && d != 0) {
-        const bool far_lo = (__builtin_amdgcn_ballot_w64(r <= 2) & mm) != 0ull, far_hi = (__builtin_amdgcn_ballot_w64(r >= S - 2) & mm) != 0ull;
-        if (d == 1 && !far_lo) d = 2;
-        if (d == -1 && !far_hi) d = -2;
+        const bool lo2 = (__builtin_amdgcn_ballot_w64(r <= 2) & mm) != 0ull, hi2 = (__builtin_amdgcn_ballot_w64(r >= S - 2) & mm) != 0ull;
+        if (d == 1 && !lo2) d = 2;      // (three planes at once, where the bundle is narrow enough, measured no better)
+        if (d == -1 && !hi2) d = -2;
     }
     return d;
 }
@@ -282,16 +282,12 @@ __device__ __forceinline__ bool follow_box(const TraceArgs &a, double *tile, Ori
 {
     auto leave = [&](auto axis, int d, int lo, int hi) {   // planes [lo, lo + |d|) or (hi - |d|, hi] leave along this axis
         constexpr int AX = decltype(axis)::value;
-        const int first = d < 0 ? hi : lo, second = d < 0 ? hi - 1 : lo + 1;
-        if (d == 2 || d == -2) {
-            if constexpr (NC == 1) {
-                retire_two_planes<T, AX>(a, tile, o, first, second, lane, edep, sXh, sYh, wc);
-            } else {
-                retire_plane<T, AX, NC>(a, tile, o, first, lane, edep, sXh, sYh, wc, coff, gstride);
-                retire_plane<T, AX, NC>(a, tile, o, second, lane, edep, sXh, sYh, wc, coff, gstride);
-            }
+        const int first = d < 0 ? hi : lo, step = d < 0 ? -1 : 1, n = d < 0 ? -d : d;
+        if constexpr (NC == 1) {
+            if (n == 2) retire_planes<T, AX, 2>(a, tile, o, first, step, lane, edep, sXh, sYh, wc);
+            else retire_plane<T, AX, NC>(a, tile, o, first, lane, edep, sXh, sYh, wc, coff, gstride);
         } else {
-            retire_plane<T, AX, NC>(a, tile, o, first, lane, edep, sXh, sYh, wc, coff, gstride);
+            for (int q = 0; q < n; ++q) retire_plane<T, AX, NC>(a, tile, o, first + q * step, lane, edep, sXh, sYh, wc, coff, gstride);
         }
     };
     const int dx = follow_plane_axis(lx - o.x, mm, T::SX);
@@ -308,8 +304,8 @@ __device__ __forceinline__ bool follow_box(const TraceArgs &a, double *tile, Ori
         dz = follow_plane_axis(lz - o.z, mm, T::SZ);
         if (dz != 0)
             retire_zplane<T, NC>(a, tile, o, dz < 0 ? o.z + T::WZ - 1 : o.z, lane, edep, sXh, sYh, wc, coff, gstride);
-        if (dz == 2 || dz == -2)
-            retire_zplane<T, NC>(a, tile, o, dz < 0 ? o.z + T::WZ - 2 : o.z + 1, lane, edep, sXh, sYh, wc, coff, gstride);
+        for (int q = 1; q < (dz < 0 ? -dz : dz); ++q)
+            retire_zplane<T, NC>(a, tile, o, dz < 0 ? o.z + T::WZ - 1 - q : o.z + q, lane, edep, sXh, sYh, wc, coff, gstride);
     }
     o.z += dz;
     const bool moved = (dx | dy | dz) != 0;
