@@ -85,5 +85,22 @@ def build_ref_shaped(verbose=False):
     return REF_SHAPED_PATH
 
 
+def build_variant(name, extra_flags=(), verbose=False):
+    """An experiment build of the same library, build_alt/libcbet_<name>.so (git-ignored; bench it with
+    CBET_LIB_PATH, scripts/alt_sweep.sh).  Never shipped."""
+    out_dir = os.path.join(ROOT, "build_alt")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, "libcbet_%s.so" % name)
+    cmd = [hipcc()] + FLAGS + list(extra_flags) + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", out] + \
+        [os.path.join(CSRC, s) for s in SOURCES] + ["-lrccl"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":   # --variant NAME [flags...]
+        print(build_variant(sys.argv[2], sys.argv[3:], verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

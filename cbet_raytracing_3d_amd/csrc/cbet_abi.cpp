@@ -237,6 +237,8 @@ int cbet_params_default(cbet_params *p, int n)
     p->max_threads = 120000000;
     p->threads_per_block = 256;
     p->ngpus = 1;
+    p->beam_lo = 0;
+    p->beam_hi = CBET_BEAMS_BY_GPU;
     p->shard_index = 0;
     p->shard_count = 1;
     p->kernel_variant = CBET_KERNEL_DEFAULT;
@@ -468,6 +470,7 @@ int cbet_context_tables(cbet_context *ctx, double **ne3d, double **kappa3d)
     if (!ctx) return fail(CBET_EINVAL, "NULL context");
     if (ne3d) *ne3d = ctx->ne3d;
     if (kappa3d) *kappa3d = ctx->kap3d;
+    ++ctx->tables_version;   // the pointers are writable: records built from the old contents are no longer trusted
     return CBET_OK;
 }
 
@@ -562,10 +565,10 @@ static int trace_impl(int b, unsigned nindices, const double *ne3d, const double
         return fail(CBET_EINVAL, "nindices=%u but def.cuh:129 gives %d for these parameters", nindices, ctx->d.nindices);
 
     int beam_lo = p->beam_lo, beam_hi = p->beam_hi;
-    if (beam_hi < beam_lo) return fail(CBET_EINVAL, "beam range [%d,%d) is reversed", beam_lo, beam_hi);
-    // "unset" is beam_lo == beam_hi == 0 only; any other empty range [k,k) is an explicit no-op (a rank that
-    // owns no beam), handled below
-    if (beam_lo == 0 && beam_hi == 0) {  // launch_ray_XZ.cu:123 with grid.x = nbeams/nGPUs (main.cu:161)
+    // "unset" is beam_hi < 0 (CBET_BEAMS_BY_GPU, the default); every empty range [k,k), [0,0) included, is an
+    // explicit no-op (a rank that owns no beam), handled below
+    if (beam_hi >= 0 && beam_hi < beam_lo) return fail(CBET_EINVAL, "beam range [%d,%d) is reversed", beam_lo, beam_hi);
+    if (beam_hi < 0) {  // launch_ray_XZ.cu:123 with grid.x = nbeams/nGPUs (main.cu:161)
         const int ng = p->ngpus > 0 ? p->ngpus : 1;
         const int per = p->nbeams / ng;
         beam_lo = b * per;
@@ -792,8 +795,12 @@ size_t cbet_cbet_slab_workspace_bytes(const cbet_params *p, int world_size, int 
     // contiguous near-equal parts, as tracer._parts
     const size_t own_beams = ((size_t)(rank + 1) * nb) / world_size - ((size_t)rank * nb) / world_size;
     const size_t own_planes = ((size_t)(rank + 1) * (p->nx + 2)) / world_size - ((size_t)rank * (p->nx + 2)) / world_size;
+    // the exchange's send and receive staging buffers (tracer._Exchanger: one peer and one component at a time): the
+    // most beams a rank owns x the most planes a rank owns x one plane, each; nothing on one rank
+    const size_t max_beams = (nb + world_size - 1) / world_size, max_planes = ((size_t)p->nx + 2 + world_size - 1) / world_size;
+    const size_t staging = world_size > 1 ? 2 * max_beams * max_planes * plane : 0;
     // own beams over the whole grid: 4 field components + gain; all beams over the own slab: 4 components + gain + scratch
-    return (5 * own_beams * hsize + 6 * nb * own_planes * plane + 2 + CBET_MAX_CBET_BEAMS) * sizeof(double);
+    return (5 * own_beams * hsize + 6 * nb * own_planes * plane + staging + 2 + CBET_MAX_CBET_BEAMS) * sizeof(double);
 }
 
 static int gain_field_impl(double *fields, const double *ne3d, double *gain, double *scratch, double *change,

@@ -2,9 +2,11 @@
 // (/root/reference/main.cu:96-232).  Same phases -- host tables, per-device upload, one launch
 // per device from its own host thread, combine, timers -- with two differences that are the point
 // of the redesign:
-//   * rays are split across devices as interleaved ray bundles (every device sees every beam),
-//     not as contiguous blocks of nbeams/nGPUs beams (launch_ray_XZ.cu:123), so 60 beams on 8
-//     devices lose nothing to integer division and the load is even;
+//   * rays are split across devices as CONTIGUOUS, equal parts of the beam-major list of ray bundles
+//     (cbet_params.shard_index / shard_count: device g of G traces bundles [T g / G, T (g+1) / G) of the T),
+//     not as blocks of nbeams/nGPUs whole beams (launch_ray_XZ.cu:123), so 60 beams on 8 devices lose
+//     nothing to integer division, the load is even to one bundle, and a device walks only its own ~7.5
+//     beams' stretch of the record table;
 //   * the per-device grids are summed on the devices by one RCCL reduce-scatter over xGMI into x-slabs
 //     (half the traffic of an all-reduce), and every device then copies ITS slab to the host over its own
 //     PCIe link, in parallel, where its host thread ADDS it into the caller's grid -- replacing the serial
@@ -16,6 +18,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -122,6 +125,11 @@ extern "C" int cbet_ray_tracing(const double *te_profile, const double *r_profil
 
     // the device grids are padded to a whole number of x-planes per device, so that the reduce-scatter hands
     // every device an equal slab (the padding planes stay zero)
+    // CBET_FORCE_RCCL=1: run the RCCL combine on one device too (a one-rank communicator: the reduce-scatter hands the
+    // device its own grid) -- lets a one-GPU box execute the communicator cache, ncclReduceScatter and the slab
+    // download that multi-device runs use (tests/test_gpu_rccl_smoke.py)
+    const char *force_env = std::getenv("CBET_FORCE_RCCL");
+    const bool use_rccl = ngpu > 1 || (force_env && force_env[0] == '1');
     const size_t plane = (size_t)(p->ny + 2) * (p->nz + 2);
     const size_t slab_planes = ((size_t)p->nx + 2 + ngpu - 1) / ngpu, slab_elems = slab_planes * plane;
     const size_t edep_bytes = sizeof(double) * slab_elems * ngpu;
@@ -148,7 +156,7 @@ extern "C" int cbet_ray_tracing(const double *te_profile, const double *r_profil
         note(j, cbet_safeGPUAlloc((void **)&j.d_te, sizeof(double) * nr, g));
         note(j, cbet_safeGPUAlloc((void **)&j.d_r, sizeof(double) * nr, g));
         note(j, cbet_safeGPUAlloc((void **)&j.d_edep, edep_bytes, g));
-        if (ngpu > 1) note(j, cbet_safeGPUAlloc((void **)&j.d_slab, sizeof(double) * slab_elems, g));
+        if (use_rccl) note(j, cbet_safeGPUAlloc((void **)&j.d_slab, sizeof(double) * slab_elems, g));
         if (j.rc) return;
         note(j, cbet_moveToAndFromGPU(j.d_beam_norm, (void *)beam_norm, sizeof(double) * 3 * p->nbeams, g));
         note(j, cbet_moveToAndFromGPU(j.d_bbeam_norm, bbeam.data(), sizeof(double) * 4 * p->nbeams, g));
@@ -211,7 +219,7 @@ extern "C" int cbet_ray_tracing(const double *te_profile, const double *r_profil
     // Combine (replaces main.cu:178-210): RCCL reduce-scatter over xGMI into x-slabs, then every device's host
     // thread copies its slab down its own PCIe link and adds it into the caller's grid ("edep +=", main.cu:206).
     int rc = CBET_OK;
-    if (ngpu > 1) {
+    if (use_rccl) {
         std::vector<int> devs(ngpu);
         for (int i = 0; i < ngpu; ++i) devs[i] = jobs[i].gpu;
         std::vector<ncclComm_t> *comms = nullptr;
@@ -229,6 +237,15 @@ extern "C" int cbet_ray_tracing(const double *te_profile, const double *r_profil
             if (nr_ == ncclSuccess) nr_ = ge;
             if (nr_ != ncclSuccess) rc = cbet::fail(CBET_ECOMM, "ncclReduceScatter: %s", ncclGetErrorString(nr_));
         }
+        if (rc != CBET_OK) {
+            // part of the group may have been enqueued: nothing may still be running on a device when release()
+            // frees its buffers below
+            for (auto &j : jobs) {
+                (void)hipSetDevice(j.gpu);
+                (void)hipStreamSynchronize(j.stream);
+            }
+            (void)hipGetLastError();
+        }
     }
     if (rc == CBET_OK) {
         auto fetch = [&](DeviceJob &j, int index) {
@@ -239,7 +256,7 @@ extern "C" int cbet_ray_tracing(const double *te_profile, const double *r_profil
             const size_t n = planes_here * plane;
             std::vector<double> staging(n);
             (void)hipSetDevice(j.gpu);
-            const double *src = ngpu > 1 ? j.d_slab : j.d_edep;
+            const double *src = use_rccl ? j.d_slab : j.d_edep;
             if (hipMemcpyAsync(staging.data(), src, n * sizeof(double), hipMemcpyDeviceToHost, j.stream) != hipSuccess ||
                 hipStreamSynchronize(j.stream) != hipSuccess) {
                 j.rc = CBET_EHIP;

@@ -214,6 +214,10 @@ __device__ __forceinline__ double phi_det(double x)
 // shard is a CONTIGUOUS 1/shard_count of that list (first_item .. first_item + count): a rank then walks ~7.5
 // whole beams of the 60 and touches only their stretch of the 537 MB record table, where an interleaved split
 // makes every rank touch every beam's (one rank's 1/8 share: 3.2 ms contiguous, 3.4 ms interleaved).
+// (Round 3 measured the alternative of visiting a share in LENGTH CLASSES -- every beam's longest bundles first,
+// beam by beam inside a class, so that a 1/8 share ends on short bundles: the launch's tail shrinks, but ~9 beams'
+// stretches of the record table are then live at once instead of ~2 and the whole pass is 15-22 % slower; a 1/8
+// share alone 3.45 ms against 3.32.  profiles/r3/experiments/length_class_order.log.)
 __device__ __forceinline__ bool work_item(const TraceArgs &a, long w, int &beam, int &patch)
 {
     const long g = a.first_item + w;

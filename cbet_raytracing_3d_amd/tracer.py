@@ -3,10 +3,12 @@
 torch is plumbing here -- device memory, streams and torch.distributed (backend "nccl" = RCCL over
 xGMI).  All computation happens in libcbet_mi355x.so through cbet_raytracing_3d_amd.api.
 
-The multi-GPU scheme replaces main.cu:166-210 (/root/reference): instead of contiguous blocks of
-nbeams/nGPUs beams per device and a host-side sum, every rank traces an interleaved 1/world_size
-share of the ray bundles of EVERY beam into its private (nx+2)(ny+2)(nz+2) grid and the grids are
-summed with one all-reduce.
+The multi-GPU scheme replaces main.cu:166-210 (/root/reference): instead of blocks of nbeams/nGPUs
+whole beams per device (60/8 truncates to 7 and drops four beams) and a host-side sum of whole grids,
+rank r traces the CONTIGUOUS part [T r / W, T (r+1) / W) of the beam-major list of T ray bundles into
+its private (nx+2)(ny+2)(nz+2) grid, and the grids are combined by one reduce-scatter into x-slabs
+(rank r ends up owning slab r of the sum: SweepPipeline, reduce_scatter_grid); allreduce_grid is kept
+for callers that need the whole sum on every rank.
 """
 import numpy as np
 import torch
@@ -135,15 +137,19 @@ class RayTracer:
                             self.params, _frozen(gain_params, frozen), self.ctx, stream)
         return gain
 
-    def cbet_solve(self, edep, gain_params, rank=0, world_size=1, group=None, fields=None, gain=None, slabs=False):
+    def cbet_solve(self, edep, gain_params, rank=0, world_size=1, group=None, fields=None, gain=None, slabs=False,
+                   force_collectives=False):
         """The CBET iteration, one rank's share (cbet_fixed_point -- or, with slabs=True, cbet_fixed_point_slabs,
         the exchange sized for xGMI -- with this device as the engine): the deposition pass is ADDED into
         `edep` (not reduced here: use allreduce_grid).  Single-rank callers can use the native loop instead:
         api.cbet_solve."""
         engine = _DeviceCbetEngine(self, edep, gain_params, fields, gain)
+        engine.force_collectives = force_collectives
         if slabs:
             rep = cbet_fixed_point_slabs(engine, gain_params, self.params.nbeams, self.grid_shape[0], rank, world_size, group)
             rep["workspace_bytes"] = engine.slab_bytes()
+            rep["exchange"] = {"chunks": engine.exchanger.chunks, "bytes_sent": engine.exchanger.bytes_sent,
+                               "staging_bytes": engine.exchanger.staging_bytes()}
         else:
             rep = cbet_fixed_point(engine, gain_params, rank, world_size, group)
         rep["gain"] = engine.gain      # all beams (all-reduce loop) / this rank's beams (slab loop), whole grid
@@ -171,12 +177,12 @@ def shard_of_rank(rank, world_size):
     return rank, world_size
 
 
-def allreduce_grid(edep, group=None):
+def allreduce_grid(edep, group=None, force=False):
     """Sum the per-rank deposition grids in place (RCCL all-reduce over xGMI with backend
     "nccl"; gloo on CPU tensors in the tests).  Replaces main.cu:178-210.  No-op without an
-    initialised process group."""
+    initialised process group.  force: run the collective on a one-rank group too (RCCL smoke test)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force):
         if edep.is_cuda and dist.get_backend(group) != "nccl":   # gloo has no device path: stage through the host
             host = edep.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
@@ -186,14 +192,14 @@ def allreduce_grid(edep, group=None):
     return edep
 
 
-def reduce_scatter_grid(grid, slab, group=None, async_op=False):
+def reduce_scatter_grid(grid, slab, group=None, async_op=False, force=False):
     """Combine the per-rank deposition grids so that rank r ends up with the SUM over ranks of x-slab r
     (`slab` = planes [r P/W, (r+1) P/W) of the plane-padded grid, P a multiple of the world size W): a
     reduce-scatter, half the xGMI traffic of the all-reduce and all a slab consumer (edepavg, a gain update, the
     host copy of a slab) needs.  RCCL with backend "nccl"; gloo (CPU tests) has no reduce-scatter for this
     layout, so there the grid is all-reduced and the slab copied out.  Returns the async work handle or None."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         slab.copy_(grid[: slab.shape[0]])
         return None
     if dist.get_backend(group) == "nccl":
@@ -222,8 +228,9 @@ class SweepPipeline:
     the serial launch -> D2H -> host sum of main.cu:166-210.  The combined result of a pass is slab r of the
     grid on rank r (reduce_scatter_grid)."""
 
-    def __init__(self, tracer, rank=0, world_size=1, group=None, overlap_traces=None):
+    def __init__(self, tracer, rank=0, world_size=1, group=None, overlap_traces=None, force_collectives=False):
         self.tr, self.rank, self.world, self.group = tracer, rank, world_size, group
+        self.force = force_collectives      # run the RCCL combine on one rank too (smoke test of the collective path)
         # a rank's share of a sharded pass is a short launch whose drain is a quarter of it: overlap consecutive
         # traces there; a whole pass on one device gains 2 % and the kernel's own duration would no longer be
         # what the events around it measure, so it keeps one trace stream
@@ -273,18 +280,21 @@ class SweepPipeline:
             if timed:
                 e1.record()
                 self.kernel_events.append((e0, e1))
+            self.work[b] = reduce_scatter_grid(self.grids[b], self.slabs[b], self.group, async_op=True, force=self.force)
+            # "grid b may be cleared again": recorded AFTER the combine was enqueued -- on one rank (and with gloo) the
+            # combine is a copy on this very stream, and pass k+2's grid.zero_() must not overtake it; with RCCL the
+            # collective runs on the process group's stream and is waited for through its work handle
             self.ev_trace[b] = torch.cuda.Event()
             self.ev_trace[b].record()
-            self.work[b] = reduce_scatter_grid(self.grids[b], self.slabs[b], self.group, async_op=True)
         return b
 
     def warm(self):
         """Run the combine once on the (zero) buffers: RCCL builds its communicator, channels and staging buffers on
         the first collective of a kind -- set-up, like the reference's cudaMalloc in its Init phase (main.cu:131-152),
         not part of a pass.  No-op on one rank."""
-        if self.world > 1:
+        if self.world > 1 or self.force:
             for b in range(2):
-                w = reduce_scatter_grid(self.grids[b], self.slabs[b], self.group, async_op=True)
+                w = reduce_scatter_grid(self.grids[b], self.slabs[b], self.group, async_op=True, force=self.force)
                 if w is not None:
                     w.wait()
             torch.cuda.synchronize(self.tr.device)
@@ -364,7 +374,10 @@ class _DeviceCbetEngine:
         tr.tabulate()
 
     def slab_bytes(self):
-        return 8 * sum(t.numel() for t in (self.own_fields, self.gain_own, self.slab_fields, self.gain_slab, self.scratch_slab))
+        """Device bytes this rank's slab loop holds: the arrays of begin_slabs and the exchange's two staging buffers."""
+        arrays = 8 * sum(t.numel() for t in (self.own_fields, self.gain_own, self.slab_fields, self.gain_slab, self.scratch_slab))
+        xch = getattr(self, "exchanger", None)
+        return arrays + (xch.staging_bytes() if xch is not None else 0)
 
     def field_passes_beams(self, use_gain, full=True):
         out = self.own_fields if full else self.own_fields[0]
@@ -426,13 +439,14 @@ def cbet_fixed_point(engine, gain_params, rank=0, world_size=1, group=None):
     (the device engine is RayTracer.cbet_solve's; the CPU tests drive this loop with an oracle engine).
     Returns {passes, converged, change, beam_gain, imbalance}."""
     si, sc = shard_of_rank(rank, world_size)
+    force = getattr(engine, "force_collectives", False)   # one rank, but every collective really runs (RCCL smoke test)
     engine.begin()
     rep = {"passes": 0, "converged": False, "change": float("inf")}
     for it in range(gain_params.max_passes):
         full = it < gain_params.direction_passes
         fields = engine.field_passes(it > 0, si, sc, full)
-        if world_size > 1:
-            allreduce_grid(fields if full else fields[0], group)
+        if world_size > 1 or force:
+            allreduce_grid(fields if full else fields[0], group, force)
         ch = _agree(engine.update_gain(fields, not full), group, world_size)
         rep["passes"] = it + 1
         rep["change"] = float(ch[0] / ch[1]) if float(ch[1]) > 0 else 0.0
@@ -440,8 +454,8 @@ def cbet_fixed_point(engine, gain_params, rank=0, world_size=1, group=None):
             rep["converged"] = True
             break
     beam_gain = engine.deposit(si, sc)
-    if world_size > 1:
-        allreduce_grid(beam_gain, group)
+    if world_size > 1 or force:
+        allreduce_grid(beam_gain, group, force)
     bg = beam_gain.cpu().numpy().copy()
     rep["beam_gain"] = bg
     rep["imbalance"] = float(abs(bg.sum()) / np.abs(bg).sum()) if np.abs(bg).sum() > 0 else 0.0
@@ -454,40 +468,102 @@ def _parts(total, world_size):
     return [((r * total) // world_size, ((r + 1) * total) // world_size) for r in range(world_size)]
 
 
-def _exchange(src, send_index, dst, recv_index, rank, world_size, group):
-    """All-to-all over point-to-point xGMI links (RCCL send/recv; gloo in the CPU tests): rank r sends
-    src[send_index(s)] to every other rank s and stores what s sends it in dst[recv_index(s)]; its own part is
-    copied.  Index tuples select strided views; the copies to and from contiguous staging buffers are the pack /
-    unpack of the exchange.  Empty parts (a rank without beams or planes) are skipped on both sides.  With a
-    backend that has no device path (gloo) device tensors are staged through the host."""
-    import torch.distributed as dist
-    dst[recv_index(rank)] = src[send_index(rank)]
-    if world_size == 1:
-        return
-    via_host = src.is_cuda and dist.get_backend(group) != "nccl"
-    ops, inbox = [], []
-    for s in range(world_size):
-        if s == rank:
-            continue
-        peer = s if group is None else dist.get_global_rank(group, s)
-        out = src[send_index(s)]
-        if out.numel():
-            out = out.contiguous()
-            ops.append(dist.P2POp(dist.isend, out.cpu() if via_host else out, peer, group))
-        want = dst[recv_index(s)]
-        if want.numel():
-            buf = torch.empty(want.shape, dtype=want.dtype, device="cpu" if via_host else want.device)
-            inbox.append((s, buf))
-            ops.append(dist.P2POp(dist.irecv, buf, peer, group))
-    if ops:
-        if src.is_cuda and not via_host:   # the staging copies are on the current stream; the collective runs on RCCL's
-            torch.cuda.current_stream(src.device).synchronize()
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-        if src.is_cuda and not via_host:
-            torch.cuda.synchronize(src.device)
-    for s, buf in inbox:
-        dst[recv_index(s)] = buf.to(dst.device)
+def exchange_staging_elems(nbeams, nx_halo, plane, world_size, force=False):
+    """Doubles in ONE staging buffer of the slab loop's exchanges (there are two: send and receive): the largest
+    chunk any exchange moves at once = the most beams a rank owns x the most planes a rank owns x one plane, for
+    one field component (cbet_cbet_slab_workspace_bytes counts 2 x this).  0 on one rank (nothing is exchanged)."""
+    if world_size <= 1 and not force:
+        return 0
+    return (-(-nbeams // world_size)) * (-(-nx_halo // world_size)) * plane
+
+
+class _Exchanger:
+    """The all-to-all exchanges of the slab-owned CBET loop over point-to-point xGMI links (RCCL send/recv; gloo in the
+    CPU tests), stream-ordered and chunked:
+
+    * no host synchronisation with RCCL: the producer's stream records an event, everything below runs on a
+      communication stream that waits for it, and the consumer's stream waits for the event recorded at the end;
+    * one peer pair at a time, in W - 1 rounds: in round k rank r sends to r + k and receives from r - k (every link
+      of the point-to-point fabric carries one message per round, no rank is the target of two senders), and a
+      multi-component array moves one component at a time: the pack copy, the grouped send/recv and the unpack copy
+      of a chunk reuse ONE send and ONE receive staging buffer (sized by exchange_staging_elems, allocated once and
+      counted in cbet_cbet_slab_workspace_bytes) instead of a contiguous copy per peer all at once;
+    * with a backend that has no device path (gloo) device tensors are staged through the host, chunk by chunk.
+
+    rank r sends src[send_index(s)] to every other rank s and stores what s sends it in dst[recv_index(s)]; its own
+    part is copied.  Index tuples select strided views, the first index being the component axis when
+    `components` is true.  Empty parts (a rank without beams or planes) are skipped on both sides."""
+
+    def __init__(self, device, staging_elems, group=None, force_collectives=False):
+        import torch.distributed as dist
+        self.group, self.device = group, torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.nccl = self.cuda and dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"
+        self.force = force_collectives      # run the send/recv machinery on one rank too (a self-exchange: RCCL smoke test)
+        self.stream = torch.cuda.Stream(device=self.device) if self.nccl else None
+        stage_dev = self.device if (self.nccl or not self.cuda) else torch.device("cpu")
+        self.send_buf = torch.empty(staging_elems, dtype=torch.float64, device=stage_dev)
+        self.recv_buf = torch.empty(staging_elems, dtype=torch.float64, device=stage_dev)
+        self.chunks = 0                     # chunks moved so far (tests, logs)
+        self.bytes_sent = 0
+
+    def staging_bytes(self):
+        return 8 * (self.send_buf.numel() + self.recv_buf.numel()) if self.send_buf.device == self.device else 0
+
+    def _chunks(self, view, components):
+        if view.numel() == 0:
+            return []
+        return [view[c] for c in range(view.shape[0])] if components else [view]
+
+    def run(self, src, send_index, dst, recv_index, rank, world_size, components=False):
+        import torch.distributed as dist
+        dst[recv_index(rank)] = src[send_index(rank)]
+        if world_size == 1 and not self.force:
+            return
+        producer = torch.cuda.current_stream(self.device) if self.nccl else None
+        if self.nccl:
+            ev = torch.cuda.Event()
+            ev.record(producer)
+            self.stream.wait_event(ev)
+        ctx = torch.cuda.stream(self.stream) if self.nccl else _NullContext()
+        with ctx:
+            rounds = range(1, world_size) if world_size > 1 else [0]      # [0]: the forced self-exchange of one rank
+            for k in rounds:
+                to, frm = (rank + k) % world_size, (rank - k) % world_size
+                outs = self._chunks(src[send_index(to)], components)
+                wants = self._chunks(dst[recv_index(frm)], components)
+                for c in range(max(len(outs), len(wants))):
+                    ops = []
+                    if c < len(outs):
+                        n = outs[c].numel()
+                        sb = self.send_buf[:n].view(outs[c].shape)
+                        sb.copy_(outs[c])                                # pack (device: on the communication stream)
+                        peer = to if self.group is None else dist.get_global_rank(self.group, to)
+                        ops.append(dist.P2POp(dist.isend, sb, peer, self.group))
+                        self.bytes_sent += 8 * n
+                    if c < len(wants):
+                        m = wants[c].numel()
+                        rb = self.recv_buf[:m].view(wants[c].shape)
+                        peer = frm if self.group is None else dist.get_global_rank(self.group, frm)
+                        ops.append(dist.P2POp(dist.irecv, rb, peer, self.group))
+                    if ops:
+                        for req in dist.batch_isend_irecv(ops):
+                            req.wait()     # RCCL: the communication stream waits (no host block); gloo: the host waits
+                        self.chunks += 1
+                    if c < len(wants):
+                        wants[c].copy_(rb)                               # unpack
+        if self.nccl:
+            done = torch.cuda.Event()
+            done.record(self.stream)
+            producer.wait_event(done)
+
+
+class _NullContext:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
 
 
 def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_size=1, group=None):
@@ -512,16 +588,21 @@ def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_s
     beams, slabs = _parts(nbeams, world_size), _parts(nx_halo, world_size)
     (b0, b1), (x0, x1) = beams[rank], slabs[rank]
     engine.begin_slabs(b0, b1, x0, x1)
+    plane = int(engine.slab_fields.shape[-1] * engine.slab_fields.shape[-2])
+    force = getattr(engine, "force_collectives", False)   # one rank, but every collective really runs (RCCL smoke test)
+    xch = _Exchanger(engine.slab_fields.device, exchange_staging_elems(nbeams, nx_halo, plane, world_size, force), group,
+                     force_collectives=force)
+    engine.exchanger = xch
     rep = {"passes": 0, "converged": False, "change": float("inf")}
     for it in range(gain_params.max_passes):
         full = it < gain_params.direction_passes
         comps = slice(None) if full else slice(0, 1)    # after the direction-building passes only the energy field moves
         own = engine.field_passes_beams(it > 0, full)
         # my beams' fields over slab s -> rank s; rank q's beams over my slab <- rank q
-        _exchange(own, lambda s: (comps, slice(None), slice(*slabs[s])),
-                  engine.slab_fields, lambda q: (comps, slice(*beams[q])), rank, world_size, group)
+        xch.run(own, lambda s: (comps, slice(None), slice(*slabs[s])),
+                engine.slab_fields, lambda q: (comps, slice(*beams[q])), rank, world_size, components=True)
         ch = engine.update_gain_slab(not full)
-        if world_size > 1:
+        if world_size > 1 or force:
             if ch.is_cuda and dist.get_backend(group) != "nccl":
                 host = ch.cpu()
                 dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
@@ -529,8 +610,8 @@ def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_s
             else:
                 dist.all_reduce(ch, op=dist.ReduceOp.SUM, group=group)
         # the gain of rank q's beams over my slab -> rank q; my beams' gain over slab s <- rank s
-        _exchange(engine.gain_slab, lambda q: (slice(*beams[q]),),
-                  engine.gain_own, lambda s: (slice(None), slice(*slabs[s])), rank, world_size, group)
+        xch.run(engine.gain_slab, lambda q: (slice(*beams[q]),),
+                engine.gain_own, lambda s: (slice(None), slice(*slabs[s])), rank, world_size)
         ch = _agree(ch, group, world_size)
         rep["passes"] = it + 1
         rep["change"] = float(ch[0] / ch[1]) if float(ch[1]) > 0 else 0.0
@@ -538,8 +619,8 @@ def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_s
             rep["converged"] = True
             break
     beam_gain = engine.deposit_beams()
-    if world_size > 1:
-        allreduce_grid(beam_gain, group)
+    if world_size > 1 or force:
+        allreduce_grid(beam_gain, group, force)
     bg = beam_gain.cpu().numpy().copy()
     rep["beam_gain"] = bg
     rep["imbalance"] = float(abs(bg.sum()) / np.abs(bg).sum()) if np.abs(bg).sum() > 0 else 0.0

@@ -40,6 +40,8 @@ extern "C" {
 #define CBET_KERNEL_LDS_COMBINE 2    /* wave-private tagged LDS write-combining of the deposits */
 #define CBET_KERNEL_LDS_WINDOW 3     /* wave-private dense LDS windows that follow the ray bundle (the default) */
 
+#define CBET_BEAMS_BY_GPU (-1)       /* cbet_params.beam_hi: no explicit beam range, use the ngpus rule */
+
 /*
  * Run-time counterpart of def.cuh's compile-time configuration (def.cuh:33-131).  Fill with
  * cbet_params_default() and override fields; every launch validates it.
@@ -56,10 +58,13 @@ typedef struct cbet_params {
     int nprofile;                /* def.cuh:33  nr, rows of the radial ne/Te profile           */
     int max_threads;             /* def.cuh:125 (enters the reference's traced-id rule)        */
     int threads_per_block;       /* def.cuh:127 (enters the reference's traced-id rule)        */
-    int ngpus;                   /* def.cuh:116 nGPUs: with beam_hi<=beam_lo, launch `b` owns  */
-                                 /* beams [b*(nbeams/ngpus), (b+1)*(nbeams/ngpus)), as at      */
-                                 /* launch_ray_XZ.cu:123                                       */
-    int beam_lo, beam_hi;        /* explicit beam range [lo,hi) overriding the ngpus rule      */
+    int ngpus;                   /* def.cuh:116 nGPUs: with beam_hi < 0 (unset, the default),  */
+                                 /* launch `b` owns beams [b*(nbeams/ngpus), (b+1)*(nbeams/ngpus)), */
+                                 /* as at launch_ray_XZ.cu:123                                 */
+    int beam_lo, beam_hi;        /* explicit beam range [lo,hi) overriding the ngpus rule;     */
+                                 /* beam_hi = CBET_BEAMS_BY_GPU (-1, what cbet_params_default  */
+                                 /* sets) = not given.  An empty range [k,k), [0,0) included,  */
+                                 /* is an explicit no-op: a rank that owns no beam traces nothing */
     int shard_index, shard_count;/* ray-bundle sharding inside the beam range: the (beam, patch) */
                                  /* list is cut into shard_count contiguous near-equal parts    */
                                  /* and part shard_index is traced (shard_count<=1: everything) */
@@ -169,7 +174,12 @@ int cbet_context_create(cbet_context **ctx, const cbet_params *p, int gpu);
 int cbet_context_destroy(cbet_context *ctx);
 /* Synchronises `stream`, copies the counters to *out and, if reset != 0, zeroes them. */
 int cbet_context_counters(cbet_context *ctx, void *stream, cbet_counters *out, int reset);
-/* Device pointers of the node tables (for tests / the 3-D plasma entry below). */
+/*
+ * Device pointers of the context's own node tables (for tests / the 3-D plasma entry below).  They are writable:
+ * the call marks the tables as modified, so the next launch that uses them (ne3d = kappa3d = NULL) rebuilds the
+ * per-node step records it gathers from.  Call it again (or cbet_prepare_step_records) after EVERY later in-place
+ * modification -- a launch cannot see a write on its own.
+ */
 int cbet_context_tables(cbet_context *ctx, double **ne3d, double **kappa3d);
 
 /*
@@ -230,8 +240,10 @@ int cbet_prepare_step_records(cbet_context *ctx, const cbet_params *p, const dou
 /*
  * rayTracing (main.cu:96-232): host profiles in, host edep (caller-owned, (nx+2)(ny+2)(nz+2)
  * doubles) ADDED into.  Uses devices gpus[0..ngpu) (NULL: 0..ngpu-1), one host thread per device;
- * rays are sharded bundle-interleaved across devices and the per-device grids are combined with
- * one RCCL all-reduce (replacing the D2H copies and host += loop of main.cu:178-210).
+ * device g of G traces the contiguous part [T g / G, T (g+1) / G) of the beam-major list of T ray bundles
+ * (no beam is lost to nbeams/nGPUs truncation), the per-device grids are combined on the devices by one
+ * RCCL reduce-scatter into x-slabs, and every device's host thread downloads ITS slab and adds it into
+ * edep (replacing the whole-grid D2H copies and the serial host += loop of main.cu:178-210).
  * beam_norm: host double[nbeams][3] (the reference reads the global table of omega_beams.h);
  * NULL = cbet_omega60_beam_norm().  timers (may be NULL) receives {init, tracing, combining,
  * total} seconds as main.cu:219-231 prints; counters (may be NULL) the summed device counters.
@@ -366,7 +378,9 @@ int cbet_gain_field_packed(double *fields, const double *ne3d, double *gain, dou
 /*
  * Device bytes one rank of the slab-owned CBET loop (tracer.cbet_fixed_point_slabs) needs beside the node tables:
  * its own beams' four field components and gain over the whole grid, all beams' fields, gain and scratch over
- * its x-slab.  0 on bad arguments.  (512^3, 60 beams, 8 ranks: ~92 GB per rank; every rank holding everything,
+ * its x-slab, and (world_size > 1) the two staging buffers of the chunked all-to-all exchanges -- one peer and one
+ * field component at a time: ceil(nbeams / W) x ceil((nx+2) / W) x (ny+2)(nz+2) doubles each.  0 on bad arguments.
+ * (512^3, 60 beams, 8 ranks: ~95 GB per rank, 2.2 GB of it staging; every rank holding everything,
  * cbet_cbet_workspace_bytes, would be 391 GB.)
  */
 size_t cbet_cbet_slab_workspace_bytes(const cbet_params *p, int world_size, int rank);

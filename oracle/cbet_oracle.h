@@ -12,12 +12,16 @@
  *   /root/reference/def.cuh:33-131  (derived constants; compile-time macros there, fields here)
  * Each function cites the lines it follows.
  *
- * Pinning (see DESIGN.md "Oracle"): the reference itself cannot be built in this image (nvcc,
- * boost/multi_array.hpp absent; the Makefile's golden file truth_100 is missing from the tree).
- * The restatement is pinned against the known answers SURVEY.md section 8(c) records for the
- * reference's own kernel source: ray-step counts at 64^3/100^3/256^3, sum/max/nonzero counts,
- * individual cell values and the md5 of the 6-significant-digit text dump at 100^3
- * (tests/test_oracle_golden.py).
+ * PARITY UNPINNED (see DESIGN.md "Oracle").  The reference's only golden file, truth_100
+ * (Makefile:14-17), is missing from the mount, its tree holds no other fixture or known-answer
+ * test, and the reference cannot be built in this image from its own sources (def.cuh includes
+ * cuda_runtime.h, H5Cpp.h and boost/multi_array.hpp; nvcc and boost are absent, and stand-in
+ * headers are not an allowed build), so oracle/_ref does not exist.  What the restatement IS
+ * checked against (tests/test_oracle_golden.py) are the numbers SURVEY.md section 8(c) recorded
+ * when the survey session compiled the reference kernel source as host C++ against stub headers:
+ * ray-step counts at 64^3/100^3/256^3, sum/max/nonzero counts, individual cell values and the md5
+ * of the 6-significant-digit text dump at 100^3.  Those are strong evidence, not a reference-held
+ * pin: nobody has compared anything here with truth_100.
  */
 #ifndef CBET_ORACLE_H_
 #define CBET_ORACLE_H_

@@ -182,7 +182,9 @@ def test_product_does_not_import_the_oracle():
 
 def test_text_writer_matches_reference_format(api, oracle, inputs, tmp_path):
     """cbet_write_text (main.cu:6-22): byte-identical to the oracle's writer on awkward values, and
-    the truth_100 md5 when fed the oracle's 100^3 grid (the reference's `make test`, Makefile:14-17)."""
+    the md5 the survey's host compile of the reference kernel recorded for the 100^3 dump (never compared
+    with truth_100, which is absent from the mount) when fed the oracle's 100^3 grid -- the reference's `make test`
+    criterion, Makefile:14-17."""
     import hashlib
     rng = np.random.default_rng(5)
     a = rng.standard_normal((3, 4, 5)) * 10.0 ** rng.integers(-8, 14, (3, 4, 5))
