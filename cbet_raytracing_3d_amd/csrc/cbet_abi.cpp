@@ -588,6 +588,9 @@ static int trace_impl(int b, unsigned nindices, const double *ne3d, const double
         return fail(CBET_EINVAL, "the CBET hooks exist for the default kernel (CBET_KERNEL_LDS_WINDOW) only");
 
     const cbet_derived &d = ctx->d;
+    // the shipped kernel keeps two per-wave step counters in 16-bit halves of a register (WaveCounters)
+    if (variant == CBET_KERNEL_LDS_WINDOW && d.nt >= 65536)
+        return fail(CBET_EINVAL, "nt = %d steps per ray: the default kernel counts a bundle's steps in 16 bits (courant_mult too small)", d.nt);
     TraceArgs a{};
     a.nx = p->nx; a.ny = p->ny; a.nz = p->nz;
     a.xmin = p->xmin; a.ymin = p->ymin; a.zmin = p->zmin;

@@ -32,6 +32,12 @@
 
 #include <type_traits>
 
+// The hand-counted vmcnt waits below assume ONE in-order vector-memory counter shared by loads, stores and atomics
+// (gfx9 / CDNA) and the gfx950 instruction set: refuse any other device target.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "cbet_trace_window.hip is written for gfx950 (CDNA4) only"
+#endif
+
 #include "cbet_trace_common.h"
 
 namespace cbet {

@@ -80,6 +80,21 @@ def test_in_flight_record_is_never_moved(listing):
                 assert not (_touched(code) & record), (name, l)
 
 
+def test_every_write_back_atomic_is_counted():
+    """record_wait(vmcnt(N <= pend)) is only right while every vector-memory instruction issued after a gather is
+    counted in WaveCounters::pend: every global_add call site of the shipped kernel sits behind a `wc.pend +=` of its
+    own (the four-component field pass waits with vmcnt(0) and is exempt).  The file refuses targets other than gfx950
+    (one in-order vmcnt shared by loads, stores and atomics)."""
+    src = open(os.path.join(CSRC, "cbet_trace_window.hip")).read().splitlines()
+    sites = [i for i, l in enumerate(src) if "global_add(a," in l and "__device__" not in l]
+    assert len(sites) >= 12
+    for i in sites:
+        window = "\n".join(src[max(0, i - 12):i + 1])
+        assert "wc.pend +=" in window or "comp_stride + own_node" in window, (i + 1, src[i])
+    text = "\n".join(src)
+    assert "#error" in text and "__gfx950__" in text
+
+
 def test_native_fp64_atomics(listing):
     """HBM and LDS adds are the native instructions, never compare-and-swap loops or flat atomics."""
     for name, body in listing.items():
