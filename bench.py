@@ -85,10 +85,12 @@ def cbet_leg(api, tr, edep, n):
             "relax": gp.relax, "tolerance": gp.tolerance}
 
 
-def measured_traffic(workload, variant):
+def measured_traffic(workload, variant, shard_count=1):
     """Per-launch counter values of the trace kernel from the committed PMC passes (profiles/r*/traffic.json:
     SQ_INSTS_VALU, TCC_EA0_ATOMIC, (2 x FETCH_SIZE + WRITE_SIZE) * 1 KiB, each collected in its own --pmc pass); the
-    newest round's entry for this workload and the shipped kernel wins.  None when there is none."""
+    newest round's entry for this workload, the shipped kernel and this share of the work (shard_count = the number of
+    ranks the bundle list is cut for; entries for K > 1 were profiled on one GPU with --shard-of K) wins.  None when
+    there is none."""
     best = None
     prof = os.path.join(ROOT, "profiles")
     for rnd in sorted(os.listdir(prof)) if os.path.isdir(prof) else []:
@@ -96,6 +98,7 @@ def measured_traffic(workload, variant):
         if os.path.exists(path):
             for e in json.load(open(path)).get("entries", []):
                 if (e.get("workload") == workload and e.get("kernel_variant") == variant and
+                        e.get("shard_count", 1) == shard_count and
                         e.get("kernel") == "k_trace_window" and "SQ_INSTS_VALU_per_launch" in e):
                     best = e
     return best
@@ -160,6 +163,9 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="cbet_params.kernel_variant (0 = default)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank flow on a 1-GPU box together with CBET_BENCH_DEVICE)")
+    ap.add_argument("--shard-of", type=int, default=0, help="profiling aid, one process: trace the middle rank's share of a "
+                    "K-rank run on this GPU (no process group; the combine is a local slab copy) -- how the per-share "
+                    "counter profiles of profiles/r*/traffic.json are collected")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cbet", action="store_true", help="skip the (unpinned) CBET-iteration leg reported beside the headline")
     args = ap.parse_args()
@@ -193,7 +199,8 @@ def main():
     workload = "omega60_%dcube_s83177_absorption" % n + ("" if args.rays_per_zone == 4 else "_rpz%d" % args.rays_per_zone)
     tr = RayTracer(p, r, ne, te, beam_norm=bn)
     d = tr.derived
-    pipe = SweepPipeline(tr, rank, world)
+    shards = args.shard_of if (world == 1 and args.shard_of > 1) else world      # parts the bundle list is cut into
+    pipe = SweepPipeline(tr, shards // 2 if shards != world else rank, shards)
 
     def fence():
         pipe.finish()
@@ -226,13 +233,17 @@ def main():
     edep_sum = tot[9].item()
     steps_total = tot[0].item()                      # ray-steps over all ranks and all K steps
     elapsed_max = tmax[2].item()
-    kernel_s_rank = tmax[3].item() / max(1, args.steps)   # slowest rank's average trace-kernel time
+    kernel_s_rank = tmax[3].item() / max(1, args.steps)   # slowest rank's average trace-kernel time (stretched when traces overlap)
     value = steps_total / elapsed_max
+    # what the launch needs when nothing runs beside it: the duration the roofline is priced with when traces overlap
+    alone = torch.tensor([pipe.time_trace_alone() if shards > 1 else kernel_s_rank], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(alone, op=dist.ReduceOp.MAX)
+    kernel_s_alone = alone.item()
 
     if rank == 0:
         steps_per_launch = steps_total / args.steps / world   # ray-steps one launch processes (avg rank)
-        traffic = measured_traffic(workload, args.variant) if world == 1 else None
-        achieved = steps_per_launch * BYTES_PER_RAY_STEP / kernel_s_rank
+        traffic = measured_traffic(workload, args.variant, shards)
         out = {
             "metric": "ray-steps/sec, OMEGA 60-beam %d^3 sweep" % n,
             "value": value, "unit": "ray-steps/s", "n_gpus": world, "steps": args.steps,
@@ -243,12 +254,19 @@ def main():
                        "edep_sum": edep_sum, "backend": args.backend if world > 1 else None,
                        "ray_steps_per_pass": steps_total / args.steps,
                        "rays_per_pass": 60 * int(d.nlive_rays), "kernel_variant": args.variant,
-                       "sharding": "contiguous 1/%d parts of the beam-major ray-bundle list, %s" % (world, COMBINE_NOTE)},
-            "roofline": roofline(traffic, steps_per_launch, kernel_s_rank, tot, steps_total),
+                       "sharding": "contiguous 1/%d parts of the beam-major ray-bundle list, %s" % (shards, COMBINE_NOTE),
+                       **({"shard_emulation": "rank %d of %d on one GPU, no process group (--shard-of): `value` is this "
+                                              "share's rate, a profiling aid, not a bench line" % (shards // 2, shards)}
+                          if shards != world else {})},
+            "roofline": roofline(traffic, steps_per_launch, kernel_s_alone, tot, steps_total),
             "pipeline": {"passes_in_flight": 2, "traces_overlap": bool(pipe.overlap_traces),
+                         "kernel_ms_in_pipeline": 1e3 * kernel_s_rank, "kernel_ms_alone": 1e3 * kernel_s_alone,
                          "note": "N > 1: consecutive passes' trace kernels run on separate streams and overlap (the drain of "
-                                 "one beside the head of the next), so roofline.kernel_ms there is a launch's stretched "
-                                 "duration, not the time it needs; N = 1 keeps one trace stream"},
+                                 "one beside the head of the next), so the events around a launch in the pipeline measure a "
+                                 "stretched duration (kernel_ms_in_pipeline); roofline.kernel_ms is kernel_ms_alone, the "
+                                 "same launch timed after the run with nothing beside it, and the counter profile is the "
+                                 "one collected for this share of the work (traffic.json shard_count); N = 1 keeps one "
+                                 "trace stream and the two are the same measurement"},
         }
         if world == 1 and not args.no_cbet:
             pipe.close()

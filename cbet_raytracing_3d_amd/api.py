@@ -113,7 +113,7 @@ EXPORTS = [
     "cbet_debug_bounds_violations",
     "cbet_gain_params_default", "cbet_gain_constants", "cbet_trace_cbet", "cbet_gain_field",
     "cbet_cbet_workspace_bytes", "cbet_cbet_solve", "cbet_gain_field_slab", "cbet_gain_field_packed",
-    "cbet_cbet_slab_workspace_bytes",
+    "cbet_cbet_slab_workspace_bytes", "cbet_pack_segments", "cbet_unpack_segments",
 ]
 
 _lib = None
@@ -176,6 +176,8 @@ def lib():
     L.cbet_gain_field.argtypes = [vp, vp, vp, vp, vp, C.POINTER(Params), C.POINTER(GainParams), vp, vp]
     L.cbet_gain_field_slab.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.POINTER(Params), C.POINTER(GainParams), vp, vp]
     L.cbet_gain_field_packed.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.POINTER(Params), C.POINTER(GainParams), vp, vp]
+    L.cbet_pack_segments.argtypes = [vp, C.c_long, C.c_int, C.c_int, vp, C.c_long, vp, vp]
+    L.cbet_unpack_segments.argtypes = [vp, C.c_long, C.c_int, C.c_int, vp, C.c_long, vp, vp]
     L.cbet_cbet_slab_workspace_bytes.argtypes = [C.POINTER(Params), C.c_int, C.c_int]
     L.cbet_cbet_slab_workspace_bytes.restype = C.c_size_t
     L.cbet_cbet_workspace_bytes.argtypes = [C.POINTER(Params)]
@@ -408,6 +410,16 @@ def gain_field_packed(fields, ne3d, gain, scratch, change, hx_lo, hx_hi, params,
     """cbet_gain_field_slab on slab-packed arrays (planes [hx_lo, hx_hi) of every beam only)."""
     _check(lib().cbet_gain_field_packed(_addr(fields), _addr(ne3d), _addr(gain), _addr(scratch), _addr(change), hx_lo, hx_hi,
                                         C.byref(params), C.byref(gain_params), ctx.handle, _addr(stream)))
+
+
+def pack_segments(src, beam_stride, hy, hz, segments, nseg, out, stream=None):
+    """cbet_pack_segments: gather the 64-byte z-runs listed in `segments` (device int32 [nseg][2]) of `src` into `out`."""
+    _check(lib().cbet_pack_segments(_addr(src), beam_stride, hy, hz, _addr(segments), nseg, _addr(out), _addr(stream)))
+
+
+def unpack_segments(dst, beam_stride, hy, hz, segments, nseg, buf, stream=None):
+    """cbet_unpack_segments: scatter `buf` (nseg runs of 8 doubles) into the listed runs of `dst`."""
+    _check(lib().cbet_unpack_segments(_addr(dst), beam_stride, hy, hz, _addr(segments), nseg, _addr(buf), _addr(stream)))
 
 
 def cbet_slab_workspace_bytes(params, world_size, rank):

@@ -698,6 +698,27 @@ int cbet_edep_average_device(const double *edep, double *edepavg, int nx, int ny
     return CBET_OK;
 }
 
+// ---- sparse exchange of the slab-owned CBET loop (cbet_grid_kernels.hip) -----------------------------------------
+int cbet_pack_segments(const double *src, long beam_stride, int hy, int hz, const int *segments, long nseg, double *out,
+                       void *stream)
+{
+    if (nseg < 0 || hy < 1 || hz < 1 || beam_stride < 0) return fail(CBET_EINVAL, "cbet_pack_segments: bad shape");
+    if (nseg > 0 && (!src || !segments || !out)) return fail(CBET_EINVAL, "cbet_pack_segments: NULL pointer");
+    if (nseg * 8 >= (1L << 31) * 256L) return fail(CBET_EINVAL, "cbet_pack_segments: too many segments for one launch");
+    CBET_HIP(launch_pack_segments(src, beam_stride, hy, hz, segments, nseg, out, (hipStream_t)stream));
+    return CBET_OK;
+}
+
+int cbet_unpack_segments(double *dst, long beam_stride, int hy, int hz, const int *segments, long nseg, const double *in,
+                         void *stream)
+{
+    if (nseg < 0 || hy < 1 || hz < 1 || beam_stride < 0) return fail(CBET_EINVAL, "cbet_unpack_segments: bad shape");
+    if (nseg > 0 && (!dst || !segments || !in)) return fail(CBET_EINVAL, "cbet_unpack_segments: NULL pointer");
+    if (nseg * 8 >= (1L << 31) * 256L) return fail(CBET_EINVAL, "cbet_unpack_segments: too many segments for one launch");
+    CBET_HIP(launch_unpack_segments(dst, beam_stride, hy, hz, segments, nseg, in, (hipStream_t)stream));
+    return CBET_OK;
+}
+
 // ---- CBET stage (parity unpinned -- see the header) ---------------------------
 static int validate_gain(const cbet_params *p, const cbet_gain_params *g)
 {

@@ -124,6 +124,10 @@ hipError_t audit_violations(unsigned long long *out, bool reset, hipStream_t str
 hipError_t launch_trace(const TraceArgs &a, int variant, bool force_idx64, hipStream_t stream);
 hipError_t launch_trace_window(const TraceArgs &a, bool force_idx64, hipStream_t stream);
 hipError_t launch_gain_field(const GainArgs &a, hipStream_t stream);
+hipError_t launch_pack_segments(const double *src, long beam_stride, int hy, int hz, const int *seg, long nseg, double *out,
+                                hipStream_t stream);
+hipError_t launch_unpack_segments(double *dst, long beam_stride, int hy, int hz, const int *seg, long nseg, const double *in,
+                                  hipStream_t stream);
 hipError_t launch_edep_average(const double *edep, double *out, int nx, int ny, int nz, hipStream_t stream);
 
 }  // namespace cbet

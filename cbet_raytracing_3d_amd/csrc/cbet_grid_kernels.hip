@@ -367,7 +367,57 @@ __global__ void __launch_bounds__(256) k_edep_average(const double *__restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sparse exchange of the slab-owned CBET loop (tracer._Exchanger): a beam's rays touch ~10 % of a slab, so what a rank
+// sends a slab owner is the list of 64-byte z-runs ("segments": 8 doubles, aligned to 8 along z) its beams can ever
+// deposit into, not the dense sub-array.  A segment is {beam (row of the array), index of the run inside one beam's
+// [planes][ny+2][ceil((nz+2)/8)] run grid}; the lists are fixed for the life of a solve (ray paths do not depend on
+// the gain) and live in device memory.  pack gathers the runs of one message into a contiguous buffer (64-B stores),
+// unpack scatters a received buffer; the run that straddles the end of a z-row is zero-filled / clipped.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pack_segments(const double *__restrict__ src, long beam_stride, int hy, int hz, int zsegs,
+                                                        const int2 *__restrict__ seg, long nseg, double *__restrict__ out)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // one double per thread: 8 threads = one 64-B run
+    if (i >= nseg * 8) return;
+    const int2 sg = seg[i >> 3];
+    const int k = (int)(i & 7), zs = sg.y % zsegs, row = sg.y / zsegs;   // row = plane * hy + y
+    const int z = 8 * zs + k;
+    out[i] = z < hz ? src[(long)sg.x * beam_stride + (long)row * hz + z] : 0.0;
+}
+
+__global__ void __launch_bounds__(256) k_unpack_segments(double *__restrict__ dst, long beam_stride, int hy, int hz, int zsegs,
+                                                          const int2 *__restrict__ seg, long nseg, const double *__restrict__ in)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nseg * 8) return;
+    const int2 sg = seg[i >> 3];
+    const int k = (int)(i & 7), zs = sg.y % zsegs, row = sg.y / zsegs;
+    const int z = 8 * zs + k;
+    if (z < hz) dst[(long)sg.x * beam_stride + (long)row * hz + z] = in[i];
+}
+
 }  // namespace
+
+hipError_t launch_pack_segments(const double *src, long beam_stride, int hy, int hz, const int *seg, long nseg, double *out,
+                                hipStream_t stream)
+{
+    if (nseg <= 0) return hipSuccess;
+    const long blocks = (nseg * 8 + 255) / 256;
+    hipLaunchKernelGGL(k_pack_segments, dim3((unsigned)blocks), dim3(256), 0, stream, src, beam_stride, hy, hz, (hz + 7) / 8,
+                       reinterpret_cast<const int2 *>(seg), nseg, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack_segments(double *dst, long beam_stride, int hy, int hz, const int *seg, long nseg, const double *in,
+                                  hipStream_t stream)
+{
+    if (nseg <= 0) return hipSuccess;
+    const long blocks = (nseg * 8 + 255) / 256;
+    hipLaunchKernelGGL(k_unpack_segments, dim3((unsigned)blocks), dim3(256), 0, stream, dst, beam_stride, hy, hz, (hz + 7) / 8,
+                       reinterpret_cast<const int2 *>(seg), nseg, in);
+    return hipGetLastError();
+}
 
 hipError_t launch_edep_average(const double *edep, double *out, int nx, int ny, int nz, hipStream_t stream)
 {

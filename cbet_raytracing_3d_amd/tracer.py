@@ -138,7 +138,7 @@ class RayTracer:
         return gain
 
     def cbet_solve(self, edep, gain_params, rank=0, world_size=1, group=None, fields=None, gain=None, slabs=False,
-                   force_collectives=False):
+                   force_collectives=False, sparse=False):
         """The CBET iteration, one rank's share (cbet_fixed_point -- or, with slabs=True, cbet_fixed_point_slabs,
         the exchange sized for xGMI -- with this device as the engine): the deposition pass is ADDED into
         `edep` (not reduced here: use allreduce_grid).  Single-rank callers can use the native loop instead:
@@ -146,10 +146,15 @@ class RayTracer:
         engine = _DeviceCbetEngine(self, edep, gain_params, fields, gain)
         engine.force_collectives = force_collectives
         if slabs:
-            rep = cbet_fixed_point_slabs(engine, gain_params, self.params.nbeams, self.grid_shape[0], rank, world_size, group)
+            rep = cbet_fixed_point_slabs(engine, gain_params, self.params.nbeams, self.grid_shape[0], rank, world_size, group,
+                                         sparse=sparse)
             rep["workspace_bytes"] = engine.slab_bytes()
+            plan = engine.exchanger.plan
             rep["exchange"] = {"chunks": engine.exchanger.chunks, "bytes_sent": engine.exchanger.bytes_sent,
-                               "staging_bytes": engine.exchanger.staging_bytes()}
+                               "staging_bytes": engine.exchanger.staging_bytes(),
+                               "sparse": plan is not None,
+                               "runs_per_exchange": plan.runs_out if plan is not None else None,
+                               "dense_fraction": (8.0 * plan.runs_out / max(1, plan.dense_out)) if plan is not None else 1.0}
         else:
             rep = cbet_fixed_point(engine, gain_params, rank, world_size, group)
         rep["gain"] = engine.gain      # all beams (all-reduce loop) / this rank's beams (slab loop), whole grid
@@ -288,6 +293,27 @@ class SweepPipeline:
             self.ev_trace[b].record()
         return b
 
+    def time_trace_alone(self, reps=3):
+        """Average duration (seconds) of this rank's trace launch when NOTHING else runs beside it: with more than one
+        rank the pipeline lets consecutive passes' trace kernels overlap, so the events around a launch there measure a
+        stretched duration; this is the time the launch needs (what a roofline fraction has to be priced with)."""
+        tr, d = self.tr, self.tr.derived
+        self.finish()
+        times = []
+        with torch.cuda.stream(self.s_trace[0]):
+            st = self.s_trace[0].cuda_stream
+            for _ in range(reps + 1):
+                self.grids[0].zero_()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                api.trace_nodes(0, d.nindices, None, None, self.grids[0], tr.d_bbeam_norm, tr.d_beam_norm, tr.d_pow_r,
+                                tr.d_phase_r, d.xconst, d.yconst, d.zconst, self.launch_p, self.ctx[0], st)
+                e1.record()
+                e1.synchronize()
+                times.append(e0.elapsed_time(e1) * 1e-3)
+        torch.cuda.synchronize(tr.device)
+        return sum(times[1:]) / reps
+
     def warm(self):
         """Run the combine once on the (zero) buffers: RCCL builds its communicator, channels and staging buffers on
         the first collective of a kind -- set-up, like the reference's cudaMalloc in its Init phase (main.cu:131-152),
@@ -374,10 +400,35 @@ class _DeviceCbetEngine:
         tr.tabulate()
 
     def slab_bytes(self):
-        """Device bytes this rank's slab loop holds: the arrays of begin_slabs and the exchange's two staging buffers."""
+        """Device bytes this rank's slab loop holds: the arrays of begin_slabs, the exchange's two staging buffers and
+        (sparse exchanges) the segment lists."""
         arrays = 8 * sum(t.numel() for t in (self.own_fields, self.gain_own, self.slab_fields, self.gain_slab, self.scratch_slab))
         xch = getattr(self, "exchanger", None)
-        return arrays + (xch.staging_bytes() if xch is not None else 0)
+        if xch is None:
+            return arrays
+        plan = getattr(xch, "plan", None)
+        return arrays + xch.staging_bytes() + (plan.list_bytes() if plan is not None else 0)
+
+    def support_mask(self):
+        """bool [own beams][X][Y][Z]: every node this rank's beams can ever deposit into -- their rays traced in the
+        reference's bookkeeping mode (absorption = 0, def.cuh:118: the energy never decays, so no ray stops before it
+        leaves the grid or runs out of steps) into beam-resolved grids.  Ray paths do not depend on the gain, so this
+        footprint contains the footprint of every pass of the iteration.  Uses own_fields[1:] as scratch (call it
+        before the first field pass)."""
+        tr, nbr = self.tr, self.b1 - self.b0
+        if nbr == 0:
+            return torch.zeros((0,) + tr.grid_shape, dtype=torch.bool, device=tr.device)
+        d = tr.derived
+        p = tr.params.copy(absorption=0, per_beam_grids=1, beam_lo=self.b0, beam_hi=self.b1, grid_beam0=self.b0, grid_beams=nbr)
+        tmp = self.own_fields[1]
+        tmp.zero_()
+        stream = torch.cuda.current_stream(tr.device).cuda_stream
+        api.trace_nodes(0, d.nindices, None, None, tmp, tr.d_bbeam_norm, tr.d_beam_norm, tr.d_pow_r, tr.d_phase_r,
+                        d.xconst, d.yconst, d.zconst, p, tr.ctx, stream)
+        mask = tmp != 0
+        tmp.zero_()
+        tr.counters(reset=True)       # the footprint pass is set-up, not part of the iteration's ray-step count
+        return mask
 
     def field_passes_beams(self, use_gain, full=True):
         out = self.own_fields if full else self.own_fields[0]
@@ -557,6 +608,170 @@ class _Exchanger:
             done.record(self.stream)
             producer.wait_event(done)
 
+    def _pack(self, arr, stride, hy, hz, seg, out):
+        n = seg.shape[0]
+        if arr.is_cuda:
+            api.pack_segments(arr, stride, hy, hz, seg, n, out, torch.cuda.current_stream(arr.device).cuda_stream)
+        else:
+            idx, valid = _pack_rows_cpu(arr, stride, hz, seg)
+            out[: 8 * n].view(n, 8).copy_(arr.reshape(-1)[idx] * valid)
+
+    def _unpack(self, arr, stride, hy, hz, seg, buf):
+        n = seg.shape[0]
+        if arr.is_cuda:
+            api.unpack_segments(arr, stride, hy, hz, seg, n, buf, torch.cuda.current_stream(arr.device).cuda_stream)
+        else:
+            idx, valid = _pack_rows_cpu(arr, stride, hz, seg)
+            arr.view(-1)[idx[valid]] = buf[: 8 * n].view(n, 8)[valid]
+
+    def run_sparse(self, src, send_index, dst, recv_index, plan, to_slabs, rank, world_size, ncomp=0):
+        """The same exchange, moving only the 64-byte z-runs of `plan` (SegmentPlan): to_slabs = exchange 1 (my beams'
+        fields to the slab owners: pack from my whole-grid array, unpack into my slab array), else exchange 2 (the gain of
+        the peers' beams over my slab back to them).  ncomp > 0: the arrays carry that many leading components, one message
+        each.  One peer pair per round, every message through the two staging buffers, stream-ordered as in run()."""
+        import torch.distributed as dist
+        dst[recv_index(rank)] = src[send_index(rank)]       # the own part: a dense local copy
+        if world_size == 1 and not self.force:
+            return
+        hy, hz = plan.Y, plan.Z
+        out_lists, in_lists = (plan.own_side, plan.slab_side) if to_slabs else (plan.slab_side, plan.own_side)
+        out_stride, in_stride = (plan.own_stride, plan.slab_stride) if to_slabs else (plan.slab_stride, plan.own_stride)
+        dev_stage = self.send_buf.device == src.device
+        producer = torch.cuda.current_stream(self.device) if self.nccl else None
+        if self.nccl:
+            ev = torch.cuda.Event()
+            ev.record(producer)
+            self.stream.wait_event(ev)
+        with (torch.cuda.stream(self.stream) if self.nccl else _NullContext()):
+            rounds = range(1, world_size) if world_size > 1 else [0]
+            for k in rounds:
+                to, frm = (rank + k) % world_size, (rank - k) % world_size
+                seg_out, seg_in = out_lists[to], in_lists[frm]
+                n_out, n_in = seg_out.shape[0], seg_in.shape[0]
+                for c in range(max(1, ncomp)):
+                    s_arr = src[c] if ncomp else src
+                    d_arr = dst[c] if ncomp else dst
+                    ops = []
+                    if n_out:
+                        if dev_stage:
+                            self._pack(s_arr, out_stride, hy, hz, seg_out, self.send_buf)
+                            sb = self.send_buf[: 8 * n_out]
+                        else:                   # gloo with device arrays: pack on the device, stage through the host
+                            tmp = torch.empty(8 * n_out, dtype=torch.float64, device=src.device)
+                            self._pack(s_arr, out_stride, hy, hz, seg_out, tmp)
+                            sb = self.send_buf[: 8 * n_out]
+                            sb.copy_(tmp)
+                        peer = to if self.group is None else dist.get_global_rank(self.group, to)
+                        ops.append(dist.P2POp(dist.isend, sb, peer, self.group))
+                        self.bytes_sent += 64 * n_out
+                    if n_in:
+                        rb = self.recv_buf[: 8 * n_in]
+                        peer = frm if self.group is None else dist.get_global_rank(self.group, frm)
+                        ops.append(dist.P2POp(dist.irecv, rb, peer, self.group))
+                    if ops:
+                        for req in dist.batch_isend_irecv(ops):
+                            req.wait()
+                        self.chunks += 1
+                    if n_in:
+                        self._unpack(d_arr, in_stride, hy, hz, seg_in, rb if dev_stage else rb.to(dst.device))
+        if self.nccl:
+            done = torch.cuda.Event()
+            done.record(self.stream)
+            producer.wait_event(done)
+
+
+def _segment_rows(support, x0, x1):
+    """Rows (beam, x - x0, y, z // 8) of the 64-byte z-runs of planes [x0, x1) in which `support` (bool
+    [beams][X][Y][Z]) is set anywhere: the unit of the sparse exchange (cbet_pack_segments)."""
+    nb, X, Y, Z = support.shape
+    zs = (Z + 7) // 8
+    sub = support[:, x0:x1]
+    if zs * 8 != Z:
+        sub = torch.nn.functional.pad(sub, (0, zs * 8 - Z))
+    return sub.reshape(nb, x1 - x0, Y, zs, 8).any(-1).nonzero().to(torch.int32)
+
+
+def _pack_rows_cpu(src, beam_stride, hz, seg):
+    """torch restatement of cbet_pack_segments for host tensors (the gloo tests); returns (values [n][8], flat index, valid)"""
+    zsegs = (hz + 7) // 8
+    rows, run = seg[:, 0].long(), seg[:, 1].long()
+    z = 8 * (run % zsegs)[:, None] + torch.arange(8)
+    valid = z < hz
+    idx = rows[:, None] * beam_stride + (run // zsegs)[:, None] * hz + z.clamp(max=hz - 1)
+    return idx, valid
+
+
+class SegmentPlan:
+    """Who sends which 64-byte z-runs to whom in the slab-owned CBET loop, fixed for the life of a solve.
+
+    `support` [own beams][X][Y][Z] marks every node this rank's beams can EVER deposit into -- the footprint of their
+    rays traced to the exit of the grid whatever their energy (ray paths do not depend on the gain; which step a ray is
+    absorbed at does) -- so the lists hold every entry any pass can make non-zero, and every entry of a beam's gain
+    coefficient its rays can read.  For each peer s the rank keeps the runs of its beams inside slab s (what it packs
+    for exchange 1 and unpacks in exchange 2), and -- received from the peers once, by send/recv -- the runs of every
+    peer q's beams inside its own slab (what it unpacks in exchange 1 and packs for exchange 2)."""
+
+    def __init__(self, support, beams, slabs, rank, world_size, group, device):
+        import torch.distributed as dist
+        nbr, X, Y, Z = support.shape
+        self.Y, self.Z, self.zsegs = Y, Z, (Z + 7) // 8
+        self.own_stride, self.slab_planes = X * Y * Z, slabs[rank][1] - slabs[rank][0]
+        self.slab_stride = self.slab_planes * Y * Z
+        b0 = beams[rank][0]
+        mine = []            # per peer s: rows (b_local, x_rel, y, zs) of my beams in slab s
+        for s in range(world_size):
+            mine.append(_segment_rows(support, *slabs[s]).cpu())
+        # the peers' rows for my slab: counts first, then the lists, point to point
+        theirs = [None] * world_size
+        theirs[rank] = mine[rank]
+        if world_size > 1:
+            cuda_nccl = dist.get_backend(group) == "nccl"
+            cdev = device if cuda_nccl else "cpu"
+            counts = torch.tensor([m.shape[0] for m in mine], dtype=torch.int64, device=cdev)
+            allc = [torch.zeros_like(counts) for _ in range(world_size)]
+            dist.all_gather(allc, counts, group=group)
+            for k in range(1, world_size):
+                to, frm = (rank + k) % world_size, (rank - k) % world_size
+                ops, rb = [], None
+                peer = lambda r_: r_ if group is None else dist.get_global_rank(group, r_)
+                if mine[to].shape[0]:
+                    ops.append(dist.P2POp(dist.isend, mine[to].to(cdev).contiguous(), peer(to), group))
+                n_in = int(allc[frm][rank])
+                if n_in:
+                    rb = torch.empty((n_in, 4), dtype=torch.int32, device=cdev)
+                    ops.append(dist.P2POp(dist.irecv, rb, peer(frm), group))
+                if ops:
+                    for req in dist.batch_isend_irecv(ops):
+                        req.wait()
+                if cuda_nccl:
+                    torch.cuda.synchronize(device)
+                theirs[frm] = rb.cpu() if rb is not None else torch.zeros((0, 4), dtype=torch.int32)
+        zs = self.zsegs
+
+        def pairs(rows, beam_offset, x_offset):
+            if rows.shape[0] == 0:
+                return torch.zeros((0, 2), dtype=torch.int32, device=device)
+            r = rows.long()
+            out = torch.stack([r[:, 0] + beam_offset, ((r[:, 1] + x_offset) * Y + r[:, 2]) * zs + r[:, 3]], 1)
+            return out.to(torch.int32).contiguous().to(device)
+        # what I address in MY whole-grid arrays (own_fields, gain_own): my beams, absolute planes, per peer slab
+        self.own_side = [pairs(mine[s], 0, slabs[s][0]) for s in range(world_size)]
+        # what I address in MY slab arrays (slab_fields, gain_slab): peer q's beams (global row), planes relative to my slab
+        self.slab_side = [pairs(theirs[q], beams[q][0], 0) for q in range(world_size)]
+        solo = world_size == 1          # the forced self-exchange of a one-rank group moves the rank's own part
+        self.max_out = max([t.shape[0] for i, t in enumerate(self.own_side) if i != rank or solo] + [0])
+        self.max_in = max([t.shape[0] for i, t in enumerate(self.slab_side) if i != rank or solo] + [0])
+        self.runs_out = sum(t.shape[0] for i, t in enumerate(self.own_side) if i != rank)    # exchange 1 sends, exchange 2 receives
+        self.runs_in = sum(t.shape[0] for i, t in enumerate(self.slab_side) if i != rank)    # exchange 1 receives, exchange 2 sends
+        self.dense_out = nbr * (X - self.slab_planes) * Y * Z      # doubles a dense exchange would send
+        del b0
+
+    def staging_elems(self):
+        return 8 * max(self.max_out, self.max_in)
+
+    def list_bytes(self):
+        return 8 * (sum(t.shape[0] for t in self.own_side) + sum(t.shape[0] for t in self.slab_side))
+
 
 class _NullContext:
     def __enter__(self):
@@ -566,7 +781,7 @@ class _NullContext:
         return False
 
 
-def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_size=1, group=None):
+def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_size=1, group=None, sparse=False):
     """The CBET fixed-point iteration with storage and exchange sized for 8 ranks on point-to-point xGMI (SURVEY
     8(f) f1; parity unpinned; same passes and same result as cbet_fixed_point).
 
@@ -590,8 +805,18 @@ def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_s
     engine.begin_slabs(b0, b1, x0, x1)
     plane = int(engine.slab_fields.shape[-1] * engine.slab_fields.shape[-2])
     force = getattr(engine, "force_collectives", False)   # one rank, but every collective really runs (RCCL smoke test)
-    xch = _Exchanger(engine.slab_fields.device, exchange_staging_elems(nbeams, nx_halo, plane, world_size, force), group,
-                     force_collectives=force)
+    # sparse = True: the exchanges move only the 64-byte z-runs a beam's rays can ever touch (SegmentPlan) instead of
+    # dense sub-arrays.  Exact, but it does not pay for this physics: traced to the exit of the grid whatever their energy
+    # -- the only footprint that is guaranteed to contain every pass's -- the refracted rays of an OMEGA beam visit 73 %
+    # of the nodes of the 256^3 grid (83 % of its z-runs), and the pack / unpack kernels of 0.8 GB take longer (0.84 ms per
+    # exchange) than the dense exchange's strided copies (0.57 ms): profiles/r3/cbet_rank_share.log.  Kept as an option
+    # for plasmas / beam sets whose footprint is small.
+    support = engine.support_mask() if (sparse and hasattr(engine, "support_mask") and (world_size > 1 or force)) else None
+    plan = SegmentPlan(support, beams, slabs, rank, world_size, group, engine.slab_fields.device) if support is not None else None
+    del support
+    staging = plan.staging_elems() if plan is not None else exchange_staging_elems(nbeams, nx_halo, plane, world_size, force)
+    xch = _Exchanger(engine.slab_fields.device, staging, group, force_collectives=force)
+    xch.plan = plan
     engine.exchanger = xch
     rep = {"passes": 0, "converged": False, "change": float("inf")}
     for it in range(gain_params.max_passes):
@@ -599,8 +824,13 @@ def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_s
         comps = slice(None) if full else slice(0, 1)    # after the direction-building passes only the energy field moves
         own = engine.field_passes_beams(it > 0, full)
         # my beams' fields over slab s -> rank s; rank q's beams over my slab <- rank q
-        xch.run(own, lambda s: (comps, slice(None), slice(*slabs[s])),
-                engine.slab_fields, lambda q: (comps, slice(*beams[q])), rank, world_size, components=True)
+        if plan is not None:
+            xch.run_sparse(own, lambda s: (comps, slice(None), slice(*slabs[s])),
+                           engine.slab_fields, lambda q: (comps, slice(*beams[q])), plan, True, rank, world_size,
+                           ncomp=4 if full else 1)
+        else:
+            xch.run(own, lambda s: (comps, slice(None), slice(*slabs[s])),
+                    engine.slab_fields, lambda q: (comps, slice(*beams[q])), rank, world_size, components=True)
         ch = engine.update_gain_slab(not full)
         if world_size > 1 or force:
             if ch.is_cuda and dist.get_backend(group) != "nccl":
@@ -610,8 +840,12 @@ def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_s
             else:
                 dist.all_reduce(ch, op=dist.ReduceOp.SUM, group=group)
         # the gain of rank q's beams over my slab -> rank q; my beams' gain over slab s <- rank s
-        xch.run(engine.gain_slab, lambda q: (slice(*beams[q]),),
-                engine.gain_own, lambda s: (slice(None), slice(*slabs[s])), rank, world_size)
+        if plan is not None:
+            xch.run_sparse(engine.gain_slab, lambda q: (slice(*beams[q]),),
+                           engine.gain_own, lambda s: (slice(None), slice(*slabs[s])), plan, False, rank, world_size)
+        else:
+            xch.run(engine.gain_slab, lambda q: (slice(*beams[q]),),
+                    engine.gain_own, lambda s: (slice(None), slice(*slabs[s])), rank, world_size)
         ch = _agree(ch, group, world_size)
         rep["passes"] = it + 1
         rep["change"] = float(ch[0] / ch[1]) if float(ch[1]) > 0 else 0.0

@@ -376,6 +376,17 @@ int cbet_gain_field_packed(double *fields, const double *ne3d, double *gain, dou
                          int hx_lo, int hx_hi, const cbet_params *p, const cbet_gain_params *g,
                          cbet_context *ctx, void *stream);
 /*
+ * The sparse exchange of the slab-owned CBET loop (tracer._Exchanger).  A segment is a 64-byte run of 8 doubles aligned
+ * to 8 along z; `segments` is a DEVICE array of nseg {row of the array (beam), index of the run inside one beam's
+ * [planes][hy][ceil(hz / 8)] run grid} int pairs.  pack: out[8 i .. 8 i + 8) = the i-th run of `src` (rows are
+ * beam_stride doubles apart, a row is [planes][hy][hz]; entries beyond the end of a z-row are written as 0);
+ * unpack: the inverse scatter (entries beyond the end of a z-row are dropped).  Stream-ordered, no synchronisation.
+ */
+int cbet_pack_segments(const double *src, long beam_stride, int hy, int hz, const int *segments, long nseg, double *out,
+                       void *stream);
+int cbet_unpack_segments(double *dst, long beam_stride, int hy, int hz, const int *segments, long nseg, const double *in,
+                         void *stream);
+/*
  * Device bytes one rank of the slab-owned CBET loop (tracer.cbet_fixed_point_slabs) needs beside the node tables:
  * its own beams' four field components and gain over the whole grid, all beams' fields, gain and scratch over
  * its x-slab, and (world_size > 1) the two staging buffers of the chunked all-to-all exchanges -- one peer and one

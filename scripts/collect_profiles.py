@@ -64,7 +64,41 @@ entry = {
               "a known 1 GiB with scripts/ubench/fetch_calib.hip (profiles/r2/fetch_calibration.log: exactly half of the bytes "
               "moved in every pattern); WRITE_SIZE checks out on k_step_table in the same pass (+3 %%)." % (dst, ", ".join("%s (%s)" % (means[c][1], c) for c in need)),
 }
-json.dump({"entries": [entry]}, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+entry["shard_count"] = 1
+entries = [entry]
+# the same counter passes for ONE rank's share of a K-rank run, profiled on one GPU (bench.py --shard-of K, the middle
+# rank's contiguous 1/K of the bundle list): what bench.py prices the roofline of an N-GPU line with
+for K in (2, 4, 8):
+    sub = os.path.join(src, "pmc_k%d" % K)
+    if not os.path.isdir(sub):
+        continue
+    os.makedirs(os.path.join(dst, "pmc_k%d" % K), exist_ok=True)
+    shutil.copy(os.path.join(sub, "summary.txt"), os.path.join(dst, "pmc_k%d" % K, "summary.txt"))
+    m = {}
+    for p in range(1, 16):
+        files = glob.glob(os.path.join(sub, "p%d" % p, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            continue
+        vals = collections.OrderedDict()
+        for r in csv.DictReader(open(files[0])):
+            k = short(r["Kernel_Name"])
+            if k and k.startswith("k_trace_window"):
+                vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        for c, v in vals.items():
+            m[c] = sum(v) / len(v)
+    if not all(c in m for c in need):
+        continue
+    entries.append({
+        "workload": entry["workload"], "kernel_variant": entry["kernel_variant"], "kernel": "k_trace_window", "shard_count": K,
+        "SQ_INSTS_VALU_per_launch": m["SQ_INSTS_VALU"], "SQ_INSTS_SALU_per_launch": m["SQ_INSTS_SALU"],
+        "SQ_INSTS_LDS_per_launch": m["SQ_INSTS_LDS"], "SQ_LDS_IDX_ACTIVE_per_launch": m["SQ_LDS_IDX_ACTIVE"],
+        "TCC_EA0_ATOMIC_requests": m["TCC_EA0_ATOMIC_sum"], "FETCH_SIZE_KiB": m["FETCH_SIZE"], "WRITE_SIZE_KiB": m["WRITE_SIZE"],
+        "hbm_bytes_per_launch": (2.0 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024.0,
+        "source": "%s/pmc_k%d/summary.txt: the rocprofv3 --pmc passes of scripts/pmc.sh run on `bench.py --shard-of %d` (rank %d's "
+                  "contiguous 1/%d of the bundle list on one GPU, no process group), mean over that share's dispatches; "
+                  "hbm = (2 x FETCH_SIZE + WRITE_SIZE) * 1024 B as for the whole launch" % (dst, K, K, K // 2, K),
+    })
+json.dump({"entries": entries}, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 print(json.dumps(entry, indent=1))
 print("per wave-step: VALU %.0f SALU %.0f LDS %.1f" % (entry["SQ_INSTS_VALU_per_launch"] / wave_steps,
       entry["SQ_INSTS_SALU_per_launch"] / wave_steps, entry["SQ_INSTS_LDS_per_launch"] / wave_steps))

@@ -69,9 +69,10 @@ trc = RayTracer(api.default_params(32, nbeams=len(beams)), r, ne, te, beam_norm=
 gp = api.default_gain_params(relax=1.0, tolerance=1e-6, max_passes=12)
 e0 = trc.new_grid()
 rep0 = trc.cbet_solve(e0, gp)
-for name, slabs in (("all-reduce loop", False), ("slab loop (chunked send/recv exchanges)", True)):
+for name, slabs, sparse in (("all-reduce loop", False, False), ("slab loop (dense chunked send/recv exchanges)", True, False),
+                            ("slab loop (sparse exchanges: pack / send-recv / unpack of z-runs)", True, True)):
     e = trc.new_grid()
-    rep = trc.cbet_solve(e, gp, slabs=slabs, force_collectives=True)
+    rep = trc.cbet_solve(e, gp, slabs=slabs, force_collectives=True, sparse=sparse)
     allreduce_grid(e, force=True)
     torch.cuda.synchronize()
     err = parity_err(e.cpu().numpy(), e0.cpu().numpy())

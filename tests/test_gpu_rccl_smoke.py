@@ -18,7 +18,7 @@ def test_torch_rccl_paths_on_a_one_rank_group():
     run = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "rccl_one_rank_smoke.py")],
                          capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert run.returncode == 0 and "RCCL SMOKE PASS" in run.stdout, run.stdout[-3000:] + run.stderr[-3000:]
-    assert run.stdout.count(" ok ") >= 5, run.stdout
+    assert run.stdout.count(" ok ") >= 6, run.stdout
 
 
 def test_native_orchestrator_reduce_scatter_on_one_device():
