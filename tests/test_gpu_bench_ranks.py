@@ -28,3 +28,22 @@ def test_two_rank_bench_rehearsal():
     assert out["config"]["ray_steps_per_pass"] == 30712072                      # SURVEY.md 8(c), 64^3: both ranks' shares
     assert out["config"]["edep_sum"] == pytest.approx(6.1070952143e17, rel=1e-9)   # the slabs of the last pass, all ranks
     assert out["value"] > 0 and out["roofline"]["kernel_ms"] > 0
+
+
+def test_two_rank_line_carries_a_roofline():
+    """The same rehearsal on the headline workload (256^3): the N = 2 line prices its roofline with the counter profile
+    collected for ONE rank's share of a 2-rank run (profiles/r*/traffic.json, shard_count 2) and with the duration of
+    that launch alone, not with the stretched duration it has while consecutive passes' traces overlap."""
+    port = 29910 + (os.getpid() % 40)
+    env = dict(os.environ, CBET_BENCH_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--grid", "256",
+           "--steps", "2", "--warmup", "1", "--no-cbet", "--no-cpu-baseline"]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert run.returncode == 0, run.stdout[-1500:] + run.stderr[-1500:]
+    out = json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][0])
+    rl, pl = out["roofline"], out["pipeline"]
+    assert out["n_gpus"] == 2 and out["config"]["ray_steps_per_pass"] == 2123497670
+    assert rl["frac"] is not None and 0.05 < rl["frac"] < 1.0 and "pmc_k2" in rl["traffic_source"]
+    assert rl["traffic"] is not None and rl["hbm_measured_frac"] > 0
+    assert pl["traces_overlap"] and pl["kernel_ms_alone"] > 0 and rl["kernel_ms"] == pytest.approx(pl["kernel_ms_alone"])
