@@ -208,6 +208,24 @@ __device__ __forceinline__ double phi_det(double x)
     return p;
 }
 
+// ... and for |x| < 2^-5 the series cut after x^7: the first dropped term, x^8 / 9!, is below 2.6e-18 of phi there, far
+// inside the rounding of the sum.  The trace kernel takes this form when EVERY live lane of the wave is that small (one
+// ballot) -- most wave-steps: K ds is a few 1e-3 outside the hot spots of the exchange -- which takes 20 of the 34
+// dependent fp64 operations out of the step's critical path.  The CPU checker always evaluates the long form; the two
+// agree to the last bit or two, and the kernel is held to the checker at 1e-9.
+__device__ __forceinline__ double phi_small(double x)
+{
+    double p = 1.0 / 40320.0;
+    p = p * x + 1.0 / 5040.0;
+    p = p * x + 1.0 / 720.0;
+    p = p * x + 1.0 / 120.0;
+    p = p * x + 1.0 / 24.0;
+    p = p * x + 1.0 / 6.0;
+    p = p * x + 0.5;
+    p = p * x + 1.0;
+    return p;
+}
+
 // The work item of workgroup `w` of a launch: which (beam, patch) bundle.  The list is beam-major -- consecutive
 // workgroups are neighbouring patches of one beam and share table lines in L2/MALL -- with each beam's patches
 // longest rays first (a globally longest-first order and a patch-major order were measured 9-17 % slower).  A

@@ -687,7 +687,8 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
                 double x = ((k01 + k23) + (k45 + k67)) * ds;
                 if (x > a.max_exponent) x = a.max_exponent;
                 if (x < -a.max_exponent) x = -a.max_exponent;
-                const double phi = phi_det(x);
+                // (dead lanes excluded from the vote: a.max_exponent bounds |x|, not the garbage a dead lane carries)
+                const double phi = (CBET_BALLOT(!(fabs(x) < 0.03125)) & live) == 0ull ? phi_small(x) : phi_det(x);
                 const double dg = s.uray * (x * phi);
                 u_eff = s.uray * phi;
                 gained += dg;
