@@ -167,6 +167,14 @@ __global__ void __launch_bounds__(256) k_gain_field(const GainArgs a)
 // to `scratch` (read-modify-write by the owning lane; the lines stay in L1/L2).  Half the pair
 // evaluations of k_gain_field and an eighth of its loads; sums are grouped by tile, so K differs
 // from the ordered kernel's in the last bits only.
+// What holds it (round 3, rocprofv3 --pmc at 256^3 / 60 beams, profiles/r3/cbet/pmc_summary.txt): 108 GB fetched
+// (2 x FETCH_SIZE) + 14 GB written per call against ~50 GB of compulsory traffic = 5.9 TB/s over 20.6 ms, 79 % of the
+// wave cycles waiting, SQ_INSTS_VALU 3.0e9 = 24 % of the vector issue rate: the re-streamed B tiles of the ~20 beams
+// present per cell miss L1 and L2 (a brick's entries are 41 KB, sixteen wavefronts per CU hold sixteen bricks).  Two
+// restructurings that read every entry once were built and measured slower: an 8-cell brick per wavefront staged in
+// LDS with the pairs dealt to 8 lanes per cell (27.6 ms: 8 wavefronts per CU, one LDS atomic pair per evaluation) and
+// one 64-cell brick per workgroup with the A tiles dealt to its four wavefronts and the sums in LDS (26.6 ms:
+// imbalance across the wavefronts, two barriers per brick) -- profiles/r3/experiments/timing_variants.log.
 constexpr int GT = 4;   // measured at 256^3, 60 beams: 2 -> 27.8 ms, 3 -> 22.5, 4 -> 20.8, 5 -> 23.2, 6 -> 22.7, 8 -> 34.8 (register pressure)
 
 struct BeamAtCell {
@@ -375,18 +383,18 @@ __global__ void __launch_bounds__(256) k_edep_average(const double *__restrict__
 // the gain) and live in device memory.  pack gathers the runs of one message into a contiguous buffer (64-B stores),
 // unpack scatters a received buffer; the run that straddles the end of a z-row is zero-filled / clipped.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_pack_segments(const double *__restrict__ src, long beam_stride, int hy, int hz, int zsegs,
+__global__ void __launch_bounds__(256) k_pack_segments(const double *__restrict__ src, long beam_stride, int hz, int zsegs,
                                                         const int2 *__restrict__ seg, long nseg, double *__restrict__ out)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // one double per thread: 8 threads = one 64-B run
     if (i >= nseg * 8) return;
     const int2 sg = seg[i >> 3];
-    const int k = (int)(i & 7), zs = sg.y % zsegs, row = sg.y / zsegs;   // row = plane * hy + y
+    const int k = (int)(i & 7), zs = sg.y % zsegs, row = sg.y / zsegs;   // row = plane * (ny + 2) + y
     const int z = 8 * zs + k;
     out[i] = z < hz ? src[(long)sg.x * beam_stride + (long)row * hz + z] : 0.0;
 }
 
-__global__ void __launch_bounds__(256) k_unpack_segments(double *__restrict__ dst, long beam_stride, int hy, int hz, int zsegs,
+__global__ void __launch_bounds__(256) k_unpack_segments(double *__restrict__ dst, long beam_stride, int hz, int zsegs,
                                                           const int2 *__restrict__ seg, long nseg, const double *__restrict__ in)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -404,7 +412,8 @@ hipError_t launch_pack_segments(const double *src, long beam_stride, int hy, int
 {
     if (nseg <= 0) return hipSuccess;
     const long blocks = (nseg * 8 + 255) / 256;
-    hipLaunchKernelGGL(k_pack_segments, dim3((unsigned)blocks), dim3(256), 0, stream, src, beam_stride, hy, hz, (hz + 7) / 8,
+    (void)hy;
+    hipLaunchKernelGGL(k_pack_segments, dim3((unsigned)blocks), dim3(256), 0, stream, src, beam_stride, hz, (hz + 7) / 8,
                        reinterpret_cast<const int2 *>(seg), nseg, out);
     return hipGetLastError();
 }
@@ -414,7 +423,8 @@ hipError_t launch_unpack_segments(double *dst, long beam_stride, int hy, int hz,
 {
     if (nseg <= 0) return hipSuccess;
     const long blocks = (nseg * 8 + 255) / 256;
-    hipLaunchKernelGGL(k_unpack_segments, dim3((unsigned)blocks), dim3(256), 0, stream, dst, beam_stride, hy, hz, (hz + 7) / 8,
+    (void)hy;
+    hipLaunchKernelGGL(k_unpack_segments, dim3((unsigned)blocks), dim3(256), 0, stream, dst, beam_stride, hz, (hz + 7) / 8,
                        reinterpret_cast<const int2 *>(seg), nseg, in);
     return hipGetLastError();
 }
