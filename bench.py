@@ -75,7 +75,55 @@ def cbet_leg(api, tr, edep, n):
     dt = time.perf_counter() - t0
     bg = np.array(rep.beam_gain[:tr.params.nbeams])
     absorbed = float(edep.sum().item())
+    # one steady-state iteration again on the solve's own arrays, each kernel timed with HIP events: the energy-field pass
+    # of all beams with the converged gain, then the gain update with frozen directions -- priced with the counts of the
+    # committed rocprofv3 --pmc passes of the same two kernels (profiles/r*/cbet/traffic.json)
+    nb, hs = tr.params.nbeams, int(np.prod(tr.grid_shape))
+    fields = ws[: 4 * nb * hs].view((4, nb) + tr.grid_shape)
+    gain = ws[4 * nb * hs: 5 * nb * hs].view((nb,) + tr.grid_shape)
+    scratch = ws[5 * nb * hs: 6 * nb * hs].view((nb,) + tr.grid_shape)
+    change = torch.zeros(2, dtype=torch.float64, device=edep.device)
+    t_field, t_gain = [], []
+    for _ in range(3):
+        fields[0].zero_()
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        e[0].record()
+        tr.launch_cbet(fields[0], gp, fields="energy", gain=gain)
+        e[1].record()
+        e[2].record()
+        tr.gain_field(fields, gain, gp, change, scratch=scratch, frozen=True)
+        e[3].record()
+        torch.cuda.synchronize()
+        t_field.append(e[0].elapsed_time(e[1]) * 1e-3)
+        t_gain.append(e[2].elapsed_time(e[3]) * 1e-3)
+    t_field, t_gain = sum(t_field[1:]) / 2, sum(t_gain[1:]) / 2
+    prof = {}
+    pdir = os.path.join(ROOT, "profiles")
+    for rnd in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        path = os.path.join(pdir, rnd, "cbet", "traffic.json")
+        if os.path.exists(path) and n == 256 and nb == 60:
+            for ent in json.load(open(path)).get("entries", []):
+                prof["gain" if "gain" in ent["kernel"] else "field"] = ent
+    alg_gain = 6.0 * nb * hs * 8     # four field components read, gain and scratch read-modify-written: the whole workspace once
+
+    def priced(ent, seconds, extra):
+        out = {"kernel_ms": 1e3 * seconds, **extra}
+        if ent is not None:
+            out.update({"bound": "hbm", "achieved": ent["hbm_bytes_per_launch"] / seconds / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                        "frac": ent["hbm_bytes_per_launch"] / seconds / HBM_PEAK, "traffic": ent["hbm_bytes_per_launch"],
+                        "valu_issue_frac": ent["SQ_INSTS_VALU_per_launch"] / seconds / VALU_ISSUE_PEAK,
+                        "wave_cycles_waiting_frac": ent["SQ_WAIT_ANY_per_launch"] / ent["SQ_WAVE_CYCLES_per_launch"],
+                        "traffic_source": ent["source"]})
+        return out
+
     return {"parity": "unpinned (no reference CBET code; model of DESIGN.md section 9)",
+            "iteration": {
+                "gain_kernel": priced(prof.get("gain"), t_gain, {
+                    "kernel": "k_gain_field_sym", "algorithmic_bytes": alg_gain, "algorithmic_GBps": alg_gain / t_gain / 1e9,
+                    "note": "measured traffic is ~2.4x the algorithmic bytes: the B tiles of every A tile are re-streamed and miss "
+                            "L1/L2 (DESIGN.md section 9); frac = (2 x FETCH_SIZE + WRITE_SIZE) / kernel time / 8 TB/s"}),
+                "energy_field_pass": priced(prof.get("field"), t_field, {"kernel": "k_trace_window<16,false,2>"}),
+                "ms": 1e3 * (t_field + t_gain)},
             "workload": "omega60_%dcube_s83177_absorption + CBET fixed-point iteration" % n,
             "passes": rep.passes, "converged": bool(rep.converged), "gain_change": rep.change,
             "energy_imbalance": rep.imbalance, "seconds": dt,
