@@ -191,6 +191,11 @@ def roofline(prof, steps_per_launch, kernel_s, tot, steps_total):
                  "peak": LDS_CYCLE_PEAK / 1e9, "unit": "G CU-cycles/s",
                  "frac": prof["SQ_LDS_IDX_ACTIVE_per_launch"] / kernel_s / LDS_CYCLE_PEAK}
                 if "SQ_LDS_IDX_ACTIVE_per_launch" in prof else None),
+        # how much of the issued vector work is the reference's own arithmetic: 62 fp64 instructions per wave-step (3 kick, 6
+        # drift, 6 cell units, 3 + 6 relocation, 3 conversions, 12 offsets and factors, 20 products, 2 absorption, 1 energy
+        # test; launch_ray_XZ.cu:268-356) at 4 issue cycles each -- the rest of `frac` is index math, window logic and selects
+        "reference_arithmetic_frac": (62.0 * prof["wave_steps_per_launch"] / kernel_s / VALU_ISSUE_PEAK
+                                      if "wave_steps_per_launch" in prof else None),
         "formula": "frac = SQ_INSTS_VALU / kernel_s / (1024 SIMDs x 2.4 GHz / 4); secondary.frac = TCC_EA0_ATOMIC x 64 B / "
                    "kernel_s / 1.3 TB/s; hbm_measured_frac = (2 x FETCH_SIZE + WRITE_SIZE) x 1 KiB / kernel_s / 8 TB/s (FETCH_SIZE tallies 128-B line requests at 64 B on gfx950: calibrated, profiles/r2/fetch_calibration.log)",
         "note": "bound = vector-instruction issue (PMC: VALU busy the largest share of SIMD cycles); the algorithmic "

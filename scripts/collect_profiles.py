@@ -88,7 +88,14 @@ for K in (2, 4, 8):
             m[c] = sum(v) / len(v)
     if not all(c in m for c in need):
         continue
+    share_steps = {}
+    share_line = os.path.join(src, "bench_share_k%d.json" % K)
+    if os.path.exists(share_line) and os.path.getsize(share_line):
+        bl = json.load(open(share_line))
+        share_steps = {"wave_steps_per_launch": bl["config"]["ray_steps_per_pass"] / 64.0 / bl["roofline"]["lane_utilisation"]}
+        shutil.copy(share_line, os.path.join(dst, "bench_share_k%d.json" % K))
     entries.append({
+        **share_steps,
         "workload": entry["workload"], "kernel_variant": entry["kernel_variant"], "kernel": "k_trace_window", "shard_count": K,
         "SQ_INSTS_VALU_per_launch": m["SQ_INSTS_VALU"], "SQ_INSTS_SALU_per_launch": m["SQ_INSTS_SALU"],
         "SQ_INSTS_LDS_per_launch": m["SQ_INSTS_LDS"], "SQ_LDS_IDX_ACTIVE_per_launch": m["SQ_LDS_IDX_ACTIVE"],
