@@ -297,9 +297,9 @@ __device__ __forceinline__ bool follow_box(const TraceArgs &a, double *tile, Ori
         }
     };
     const int dx = follow_plane_axis(lx - o.x, mm, T::SX);
+    const int dy = follow_plane_axis(ly - o.y, mm, T::SY);
     if (dx != 0) leave(std::integral_constant<int, 0>{}, dx, o.x, o.x + T::WX - 1);
     o.x += dx;
-    const int dy = follow_plane_axis(ly - o.y, mm, T::SY);
     if (dy != 0) leave(std::integral_constant<int, 1>{}, dy, o.y, o.y + T::WY - 1);
     o.y += dy;
     int dz;
