@@ -174,7 +174,9 @@ __global__ void __launch_bounds__(256) k_gain_field(const GainArgs a)
 // restructurings that read every entry once were built and measured slower: an 8-cell brick per wavefront staged in
 // LDS with the pairs dealt to 8 lanes per cell (27.6 ms: 8 wavefronts per CU, one LDS atomic pair per evaluation) and
 // one 64-cell brick per workgroup with the A tiles dealt to its four wavefronts and the sums in LDS (26.6 ms:
-// imbalance across the wavefronts, two barriers per brick) -- profiles/r3/experiments/timing_variants.log.
+// imbalance across the wavefronts, two barriers per brick) -- profiles/r3/experiments/timing_variants.log.  Occupancy: 162
+// registers give 12 wavefronts per CU; capped at 8 by a dummy LDS allocation 24.6 ms, at 4: 38.5 ms; forced to 128 registers
+// (16 wavefronts, 20 spilled) 20.2 ms -- it wants wavefronts in flight as much as it wants bytes.
 constexpr int GT = 4;   // measured at 256^3, 60 beams: 2 -> 27.8 ms, 3 -> 22.5, 4 -> 20.8, 5 -> 23.2, 6 -> 22.7, 8 -> 34.8 (register pressure)
 
 struct BeamAtCell {

@@ -717,7 +717,6 @@ class SegmentPlan:
         self.Y, self.Z, self.zsegs = Y, Z, (Z + 7) // 8
         self.own_stride, self.slab_planes = X * Y * Z, slabs[rank][1] - slabs[rank][0]
         self.slab_stride = self.slab_planes * Y * Z
-        b0 = beams[rank][0]
         mine = []            # per peer s: rows (b_local, x_rel, y, zs) of my beams in slab s
         for s in range(world_size):
             mine.append(_segment_rows(support, *slabs[s]).cpu())
@@ -764,7 +763,6 @@ class SegmentPlan:
         self.runs_out = sum(t.shape[0] for i, t in enumerate(self.own_side) if i != rank)    # exchange 1 sends, exchange 2 receives
         self.runs_in = sum(t.shape[0] for i, t in enumerate(self.slab_side) if i != rank)    # exchange 1 receives, exchange 2 sends
         self.dense_out = nbr * (X - self.slab_planes) * Y * Z      # doubles a dense exchange would send
-        del b0
 
     def staging_elems(self):
         return 8 * max(self.max_out, self.max_in)
