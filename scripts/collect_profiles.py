@@ -19,6 +19,12 @@ if os.path.exists(os.path.join(src, "cbet", "kernel_stats.csv")):
                 fo.write(line)
 
 
+if os.path.exists(os.path.join(src, "cbet_pmc", "summary.txt")):
+    shutil.copy(os.path.join(src, "cbet_pmc", "summary.txt"), os.path.join(dst, "cbet", "pmc_summary.txt"))
+if os.path.exists(os.path.join(src, "cbet_rank_share.log")):
+    shutil.copy(os.path.join(src, "cbet_rank_share.log"), os.path.join(dst, "cbet_rank_share.log"))
+
+
 def short(k):
     for name in ("k_trace_window", "k_step_table", "k_tabulate"):
         if name in k:

@@ -25,4 +25,6 @@ done
 python3 scripts/shard_timing.py 256 > "$OUT/shard_timing.log" 2>/dev/null
 python3 scripts/launch_size_curve.py > "$OUT/launch_size_curve.log" 2>/dev/null
 bash scripts/cbet_profile.sh "$TAG/cbet" > "$OUT/cbet_profile.log" 2>&1
+bash scripts/cbet_gain_pmc.sh "$TAG/cbet_pmc" > "$OUT/cbet_pmc.log" 2>&1; echo "cbet pmc rc=$?"
+timeout -k 10 400 python3 scripts/cbet_rank_share.py 8 256 64 2>/dev/null > "$OUT/cbet_rank_share.log"
 tail -3 "$OUT/pmc.log"; cat "$OUT/shard_timing.log"
