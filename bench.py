@@ -81,7 +81,6 @@ def cbet_leg(api, tr, edep, n):
     nb, hs = tr.params.nbeams, int(np.prod(tr.grid_shape))
     fields = ws[: 4 * nb * hs].view((4, nb) + tr.grid_shape)
     gain = ws[4 * nb * hs: 5 * nb * hs].view((nb,) + tr.grid_shape)
-    scratch = ws[5 * nb * hs: 6 * nb * hs].view((nb,) + tr.grid_shape)
     change = torch.zeros(2, dtype=torch.float64, device=edep.device)
     t_field, t_gain = [], []
     for _ in range(3):
@@ -91,7 +90,7 @@ def cbet_leg(api, tr, edep, n):
         tr.launch_cbet(fields[0], gp, fields="energy", gain=gain)
         e[1].record()
         e[2].record()
-        tr.gain_field(fields, gain, gp, change, scratch=scratch, frozen=True)
+        tr.gain_field(fields, gain, gp, change, pair_once=True, frozen=True)
         e[3].record()
         torch.cuda.synchronize()
         t_field.append(e[0].elapsed_time(e[1]) * 1e-3)
@@ -104,7 +103,7 @@ def cbet_leg(api, tr, edep, n):
         if os.path.exists(path) and n == 256 and nb == 60:
             for ent in json.load(open(path)).get("entries", []):
                 prof["gain" if "gain" in ent["kernel"] else "field"] = ent
-    alg_gain = 6.0 * nb * hs * 8     # four field components read, gain and scratch read-modify-written: the whole workspace once
+    alg_gain = 5.0 * nb * hs * 8     # the whole workspace once: four field components and the gain
 
     def priced(ent, seconds, extra):
         out = {"kernel_ms": 1e3 * seconds, **extra}
@@ -120,8 +119,10 @@ def cbet_leg(api, tr, edep, n):
             "iteration": {
                 "gain_kernel": priced(prof.get("gain"), t_gain, {
                     "kernel": "k_gain_field_sym", "algorithmic_bytes": alg_gain, "algorithmic_GBps": alg_gain / t_gain / 1e9,
-                    "note": "measured traffic is ~2.4x the algorithmic bytes: the B tiles of every A tile are re-streamed and miss "
-                            "L1/L2 (DESIGN.md section 9); frac = (2 x FETCH_SIZE + WRITE_SIZE) / kernel time / 8 TB/s"}),
+                    "note": "every entry is read once, the cell's beams are staged in LDS (DESIGN.md section 9); measured traffic is "
+                            "~1.25x the workspace (z-runs of 16 cells straddle 128-byte lines: the row pitch is nz+2 doubles); "
+                            "frac = (2 x FETCH_SIZE + WRITE_SIZE) / kernel time / 8 TB/s; the kernel is vector-issue bound "
+                            "(valu_issue_frac), not HBM bound"}),
                 "energy_field_pass": priced(prof.get("field"), t_field, {"kernel": "k_trace_window<16,false,2>"}),
                 "ms": 1e3 * (t_field + t_gain)},
             "workload": "omega60_%dcube_s83177_absorption + CBET fixed-point iteration" % n,

@@ -823,8 +823,9 @@ size_t cbet_cbet_slab_workspace_bytes(const cbet_params *p, int world_size, int 
     // most beams a rank owns x the most planes a rank owns x one plane, each; nothing on one rank
     const size_t max_beams = (nb + world_size - 1) / world_size, max_planes = ((size_t)p->nx + 2 + world_size - 1) / world_size;
     const size_t staging = world_size > 1 ? 2 * max_beams * max_planes * plane : 0;
-    // own beams over the whole grid: 4 field components + gain; all beams over the own slab: 4 components + gain + scratch
-    return (5 * own_beams * hsize + 6 * nb * own_planes * plane + staging + 2 + CBET_MAX_CBET_BEAMS) * sizeof(double);
+    // own beams over the whole grid: 4 field components + gain; all beams over the own slab: 4 components + gain
+    // (the pair-once gain kernel keeps its sums in LDS: no scratch array since round 3)
+    return (5 * own_beams * hsize + 5 * nb * own_planes * plane + staging + 2 + CBET_MAX_CBET_BEAMS) * sizeof(double);
 }
 
 static int gain_field_impl(double *fields, const double *ne3d, double *gain, double *scratch, double *change,
@@ -866,7 +867,7 @@ size_t cbet_cbet_workspace_bytes(const cbet_params *p)
 {
     if (!p || validate(p) != CBET_OK) return 0;
     const size_t hsize = (size_t)(p->nx + 2) * (p->ny + 2) * (p->nz + 2);
-    return (6 * (size_t)p->nbeams * hsize + 2 + CBET_MAX_CBET_BEAMS) * sizeof(double);
+    return (5 * (size_t)p->nbeams * hsize + 2 + CBET_MAX_CBET_BEAMS) * sizeof(double);   // 4 field components + gain
 }
 
 int cbet_cbet_solve(double *te_data_g, double *r_data_g, double *ne_data_g, double *edep,
@@ -897,8 +898,8 @@ int cbet_cbet_solve(double *te_data_g, double *r_data_g, double *ne_data_g, doub
         if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? CBET_ENOMEM : CBET_EHIP, "hipMalloc(cbet workspace, %zu bytes): %s", bytes, hipGetErrorString(e));
         own = true;
     }
-    double *fields = ws, *gain = ws + 4 * nb * hsize, *scratch = gain + nb * hsize, *change = scratch + nb * hsize,
-           *beam_gain = change + 2;
+    double *fields = ws, *gain = ws + 4 * nb * hsize, *change = gain + nb * hsize, *beam_gain = change + 2;
+    double *const pair_once = gain;   // any non-NULL pointer selects the pair-once gain kernel; it is not dereferenced
     int rc = CBET_OK;
     cbet_counters c0{}, c1{};
     cbet_cbet_report rep{};
@@ -928,7 +929,7 @@ int cbet_cbet_solve(double *te_data_g, double *r_data_g, double *ne_data_g, doub
             }
             CBET_HIP(hipMemsetAsync(change, 0, 2 * sizeof(double), s));
             gg.directions_frozen = full ? 0 : 1;
-            if (int r = gain_field_impl(fields, nullptr, gain, scratch, change, 0, p->nx + 2, false, p, &gg, ctx, stream, true)) return r;
+            if (int r = gain_field_impl(fields, nullptr, gain, pair_once, change, 0, p->nx + 2, false, p, &gg, ctx, stream, true)) return r;
             double hc[2];
             CBET_HIP(hipMemcpyAsync(hc, change, sizeof hc, hipMemcpyDeviceToHost, s));
             CBET_HIP(hipStreamSynchronize(s));

@@ -161,165 +161,295 @@ __global__ void __launch_bounds__(256) k_gain_field(const GainArgs a)
 }
 
 
-// The same update with every unordered beam pair evaluated ONCE (G_ji = -G_ij exactly: eta changes sign,
-// P is odd): the present beams of a brick are taken in tiles of GT, a tile pair (A, B) is GT x GT
-// statically unrolled pair bodies on registers, A's sums stay in registers across its B tiles and B's go
-// to `scratch` (read-modify-write by the owning lane; the lines stay in L1/L2).  Half the pair
-// evaluations of k_gain_field and an eighth of its loads; sums are grouped by tile, so K differs
-// from the ordered kernel's in the last bits only.
-// What holds it (round 3, rocprofv3 --pmc at 256^3 / 60 beams, profiles/r3/cbet/pmc_summary.txt): 108 GB fetched
-// (2 x FETCH_SIZE) + 14 GB written per call against ~50 GB of compulsory traffic = 5.9 TB/s over 20.6 ms, 79 % of the
-// wave cycles waiting, SQ_INSTS_VALU 3.0e9 = 24 % of the vector issue rate: the re-streamed B tiles of the ~20 beams
-// present per cell miss L1 and L2 (a brick's entries are 41 KB, sixteen wavefronts per CU hold sixteen bricks).  Two
-// restructurings that read every entry once were built and measured slower: an 8-cell brick per wavefront staged in
-// LDS with the pairs dealt to 8 lanes per cell (27.6 ms: 8 wavefronts per CU, one LDS atomic pair per evaluation) and
-// one 64-cell brick per workgroup with the A tiles dealt to its four wavefronts and the sums in LDS (26.6 ms:
-// imbalance across the wavefronts, two barriers per brick) -- profiles/r3/experiments/timing_variants.log.  Occupancy: 162
-// registers give 12 wavefronts per CU; capped at 8 by a dummy LDS allocation 24.6 ms, at 4: 38.5 ms; forced to 128 registers
-// (16 wavefronts, 20 spilled) 20.2 ms -- it wants wavefronts in flight as much as it wants bytes.
-constexpr int GT = 4;   // measured at 256^3, 60 beams: 2 -> 27.8 ms, 3 -> 22.5, 4 -> 20.8, 5 -> 23.2, 6 -> 22.7, 8 -> 34.8 (register pressure)
-
 struct BeamAtCell {
     double I, kx, ky, kz;
 };
 
-// pref * P(eta_ij) for the pair (i, j); zero intensities make the products vanish, no branch needed
-__device__ __forceinline__ double pair_gain(const BeamAtCell &bi, const BeamAtCell &bj, double ux, double uy, double uz,
-                                            double cs, double iaw2, double pref)
+// ---------------------------------------------------------------------------------------------
+// The same update with every unordered beam pair evaluated ONCE (G_ji = -G_ij exactly: eta changes sign, P is odd) and
+// every entry read from memory ONCE: one wavefront (= one workgroup) per run of LC = 16 cells along z, LG = 4 lanes per
+// cell, the run's present beams staged in LDS.
+//   masks  : lane (cell, g) loads beam 4 r + g in round r, all rounds in flight; the values are transposed through LDS
+//            so that lane b holds beam b's sixteen entries and one compare per cell accumulates the masks of the beams
+//            that touched the run (E != 0 somewhere) and that are present in it (E > 0 somewhere) in scalar registers.
+//   phase 1: the touched beams, four per round: normalise the entry as k_gain_field does, write it back, and stage
+//            (I, kx, ky, kz) of the present beams in LDS, compacted to slots, with a zeroed sum beside them.
+//   phase 2: the slots in tiles of four.  Inside a tile lane group g pairs its own beam with the next and (g < 2) the
+//            next but one, cyclically -- six pairs in two evaluations; against the later tiles the A tile sits in the
+//            registers of all four lanes of the cell and lane group g takes slot g of every B tile, so its sum for that
+//            B beam is complete (no atomics) and the four partial sums of the A beams are folded across the lane groups
+//            once per A tile.
+//   phase 3: every beam's gain relaxes towards its sum (zero where the beam is absent from the cell).
+// A run crossed by more beams than LDS has slots for (LCAP = 20) is taken in halves or quarters: fewer cells, more slots.
+// LDS 5 arrays x LCAP x LC doubles = 12.8 KB and 168 registers: twelve wavefronts per CU.  The plasma state of a cell
+// (cell_state: two square roots, five divisions) is computed for 64 cells at a time and handed out by lane shuffles.
+// The sums live in LDS: GainArgs.scratch only selects this kernel, it is never dereferenced.
+//
+// Measured (round 3, 256^3, 60 beams, frozen directions; profiles/r3/cbet_gain/): 11.5 ms against 19.2 ms for the kernel
+// it replaces (tiles re-streamed from memory, sums in a scratch array: 108 GB fetched + 14 GB written per call, every
+// B tile of a brick's ~41 KB missing L1 and L2); 46 GB fetched + 5.6 GB written, SQ_INSTS_VALU 3.6e9 at 61 % of the
+// vector issue rate.  What was tried on the way (profiles/r3/experiments/gain_kernel.log): the whole grid's 4 waves per
+// CU with 64 slots (27.9 ms), exact IEEE pair function (12.5 ms at the same occupancy), masks by ballots and scalar bit
+// tests (+530 SALU per run, 11.8 -> 11.4 ms when replaced), LDS-DMA prefetch of the next run's lines (13.4 ms), LCAP
+// 16 / 24 / 28 / 32 (13.0 / 12.0 / 13.2 / 13.4 ms), an XCD-contiguous brick order for the old kernel (23.2 ms: the
+// central slabs are the heavy ones) and 2x2x16 / 1x4x16 bricks for it (20.6 / 26 ms).
+// ---------------------------------------------------------------------------------------------
+constexpr int LC = 16, LG = 4, LCAP = 20, LROUNDS = 64 / LG;
+constexpr int LCH = 4, LCH3 = 8;   // rounds whose loads are in flight together in phase 1 / phase 3
+
+// pref * P(eta_ij) as ONE quotient: with N = -(q . u) and D = |q| cs + 1e-10 (eta = N / D),
+//   P = iaw^2 eta / ((eta^2 - 1)^2 + iaw^2 eta^2) = iaw^2 N D^3 / ((N^2 - D^2)^2 + iaw^2 N^2 D^2),
+// square root and reciprocal by the hardware estimates and Newton steps (a few ulp; the sums of the symmetric kernels are
+// grouped differently from the ordered kernel's anyway).  q = 0 (a beam against itself, or two parallel beams) gives
+// N = 0 over D^4 = 1e-40: zero, as in pair_gain.
+__device__ __forceinline__ double pair_gain_fast(const BeamAtCell &bi, const BeamAtCell &bj, double ux, double uy, double uz,
+                                                 double cs, double iaw2, double pref_iaw2)
 {
     const double qx = bj.kx - bi.kx, qy = bj.ky - bi.ky, qz = bj.kz - bi.kz;
-    const double kiaw = sqrt(qx * qx + qy * qy + qz * qz);
-    const double eta = (0.0 - (qx * ux + qy * uy + qz * uz)) / (kiaw * cs + 1e-10);
-    const double e2 = eta * eta;
-    const double P = iaw2 * eta / ((e2 - 1.0) * (e2 - 1.0) + iaw2 * e2);
-    return pref * P;
+    const double q2 = fmax(__builtin_fma(qz, qz, __builtin_fma(qy, qy, qx * qx)), 1e-280);
+    // |q| = sqrt(q2): one Goldschmidt step from the reciprocal-square-root estimate, one correction
+    const double r0 = __builtin_amdgcn_rsq(q2);
+    double gq = q2 * r0, hq = 0.5 * r0;
+    const double e = __builtin_fma(-hq, gq, 0.5);
+    gq = __builtin_fma(gq, e, gq); hq = __builtin_fma(hq, e, hq);
+    gq = __builtin_fma(__builtin_fma(-gq, gq, q2), hq, gq);
+    const double N = -__builtin_fma(qz, uz, __builtin_fma(qy, uy, qx * ux));
+    const double D = __builtin_fma(gq, cs, 1e-10);
+    const double N2 = N * N, D2 = D * D, t = N2 - D2;
+    const double den = __builtin_fma(t, t, (iaw2 * N2) * D2);
+    const double num = ((pref_iaw2 * N) * D) * D2;
+    // num / den: reciprocal estimate, one Newton step, one correction of the quotient
+    double y = __builtin_amdgcn_rcp(den);
+    y = __builtin_fma(__builtin_fma(-den, y, 1.0), y, y);
+    const double qt = num * y;
+    return __builtin_fma(__builtin_fma(-den, qt, num), y, qt);
 }
 
-__global__ void __launch_bounds__(256) k_gain_field_sym(const GainArgs a)
+// LDS traffic between lanes of ONE wavefront: the hardware keeps a wavefront's LDS instructions in order, the compiler
+// has to be told that they may not be reordered across this point
+__device__ __forceinline__ void lds_order()
 {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ void __launch_bounds__(64, 3) k_gain_field_sym(const GainArgs a)
+{
+    static_assert(5 * LCAP * LC >= 64 * (LC + 1), "the slot arrays double as the staging area of the presence masks");
+    __shared__ double lds[5 * LCAP * LC];
+    double *const sI = lds, *const sX = sI + LCAP * LC, *const sY = sX + LCAP * LC, *const sZ = sY + LCAP * LC,
+                 *const sR = sZ + LCAP * LC;
     const int HY = a.ny + 2, HZ = a.nz + 2;
-    const long hsize = a.bstride;                 // entries stored per beam (the whole haloed grid, or one x-slab of it)
+    const long hsize = a.bstride;
     const long total = hsize * a.nbeams;
-    const int bx0 = a.hx_lo >> 1, bx = ((a.hx_hi + 1) >> 1) - bx0;   // brick columns touching the slab [hx_lo, hx_hi)
-    const int by = (HY + 3) / 4, bz = (HZ + 7) / 8;
-    const long bricks = (long)bx * by * bz;
-    const int lane = threadIdx.x & (kWave - 1);
-    const long wave0 = (long)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
-    const long nwaves = (long)gridDim.x * (blockDim.x / kWave);
+    const int zb = (HZ + LC - 1) / LC;
+    const long rows = (long)(a.hx_hi - a.hx_lo) * HY;
+    const int lane = threadIdx.x, c = lane & (LC - 1), g = lane >> 4;
     const double iaw2 = a.iaw * a.iaw;
+    const int rounds = (a.nbeams + LG - 1) / LG;
     double sum_change = 0.0, sum_abs = 0.0;
-    for (long brick = wave0; brick < bricks; brick += nwaves) {
-        const int ibz = (int)(brick % bz);
-        const long t = brick / bz;
-        const int iby = (int)(t % by), ibx = bx0 + (int)(t / by);
-        const int hi = 2 * ibx + (lane >> 5), hj = 4 * iby + ((lane >> 3) & 3), hk = 8 * ibz + (lane & 7);
-        const bool valid = hi >= a.hx_lo && hi < a.hx_hi && hj < HY && hk < HZ;
-        const long h = valid ? ((long)hi * HY + hj) * HZ + hk : a.store0;
-        const long hs = h - a.store0;               // index into the (possibly slab-packed) arrays
-        double *fI = a.fields + hs, *fx = fI + total, *fy = fx + total, *fz = fy + total;
-        double *raw = a.scratch + hs;
-        const CellState c = cell_state(a, h);
-        const double kmag = a.k0 * c.rt;
-        const double ds_node = (kC * c.rt) * a.dt;
-        unsigned long long mask = 0ull;
-        for (int b = 0; b < a.nbeams; ++b) {  // phase 1: as k_gain_field, plus the scratch sums start at zero
-            const long o = (long)b * hsize;
-            const double E = valid ? fI[o] : 0.0;
-            if (__builtin_amdgcn_ballot_w64(E != 0.0) == 0ull) continue;   // no ray of this beam came near the brick
-            if (E != 0.0) normalise_entry(a, c, kmag, ds_node, E, fI, fx, fy, fz, o);   // also clears a non-positive E
-            if (__builtin_amdgcn_ballot_w64(E > 0.0) == 0ull) continue;
-            mask |= 1ull << b;
-            if (valid) raw[o] = 0.0;
-        }
-        const double pref = (valid && c.eps > 0.0) ? a.gain_const * c.frac * (1.0 / a.iaw) / c.rt : 0.0;
-        auto load_tile = [&](unsigned long long &m, int (&id)[GT], BeamAtCell (&bm)[GT]) {
+    double st_rt = 0.0, st_ux = 0.0, st_uy = 0.0, st_uz = 0.0, st_pref = 0.0;
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int hi = a.hx_lo + (int)(row / HY), hj = (int)(row % HY);
+        for (int ibz = 0; ibz < zb; ++ibz) {
+            const int hk = LC * ibz + c;
+            const bool valid = hk < HZ;
+            const long h = ((long)hi * HY + hj) * HZ + (valid ? hk : 0);
+            const long hs = h - a.store0;
+            double *fI = a.fields + hs, *fx = fI + total, *fy = fx + total, *fz = fy + total;
+            // ---- which beams touched the run (E != 0 somewhere), which are present (E > 0 somewhere): every round's
+            //      load in flight together, transposed through LDS so that lane b sees beam b's sixteen entries and one
+            //      compare per cell accumulates the masks (bit b = lane b) in scalar registers
+            unsigned long long mask = 0ull, touched = 0ull;
+            {
+                double E[LROUNDS];
 #pragma unroll
-            for (int s = 0; s < GT; ++s) {
-                id[s] = -1;
-                bm[s].I = 0.0; bm[s].kx = 0.0; bm[s].ky = 0.0; bm[s].kz = 0.0;
-                if (m != 0ull) {
-                    id[s] = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    const long o = (long)id[s] * hsize;
-                    const double I = fI[o];
-                    bm[s].I = I > 0.0 ? I : 0.0;          // an absent beam's entry is whatever was deposited: mask it
-                    bm[s].kx = fx[o]; bm[s].ky = fy[o]; bm[s].kz = fz[o];
+                for (int r = 0; r < LROUNDS; ++r) {
+                    const int b = LG * r + g;
+                    E[r] = (r < rounds && b < a.nbeams && valid) ? fI[(long)b * hsize] : 0.0;
+                }
+                __syncthreads();                 // the previous run's LDS reads are done
+#pragma unroll
+                for (int r = 0; r < LROUNDS; ++r) lds[(LG * r + g) * (LC + 1) + c] = E[r];
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < LC; ++k) {
+                    const double e = lds[lane * (LC + 1) + k];
+                    mask |= __builtin_amdgcn_ballot_w64(e > 0.0);
+                    touched |= __builtin_amdgcn_ballot_w64(e != 0.0);
                 }
             }
-        };
-        unsigned long long ma = mask;
-        while (ma != 0ull) {
-            int aid[GT];
-            BeamAtCell A[GT];
-            load_tile(ma, aid, A);
-            double KA[GT];
+            const int n = __popcll(mask), tiles = (n + LG - 1) / LG;
+            // the plasma state of 64 cells at a time (lane = cell), handed to the four runs they make up
+            if ((ibz & 3) == 0) {
+                const int hk64 = LC * ibz + lane;
+                const CellState c64 = cell_state(a, ((long)hi * HY + hj) * HZ + (hk64 < HZ ? hk64 : HZ - 1));
+                st_rt = c64.rt; st_ux = c64.ux; st_uy = c64.uy; st_uz = c64.uz;
+                st_pref = c64.eps > 0.0 ? a.gain_const * c64.frac * (1.0 / a.iaw) / c64.rt : 0.0;
+            }
+            const int from = LC * (ibz & 3) + c;
+            const double rt = __shfl(st_rt, from, kWave), ux = __shfl(st_ux, from, kWave), uy = __shfl(st_uy, from, kWave),
+                         uz = __shfl(st_uz, from, kWave);
+            const double pref = valid ? __shfl(st_pref, from, kWave) : 0.0;
+            const bool subcritical = rt > 0.0;   // eps > 0
+            const double kmag = a.k0 * rt;
+            const double ds_node = (kC * rt) * a.dt;
+            const double pref_iaw2 = pref * iaw2;
+            // a run crossed by more beams than LDS has slots for is taken in halves or quarters (fewer cells, more slots)
+            const int sh = n <= LCAP ? 4 : (n <= 2 * LCAP ? 3 : 2), lc = 1 << sh, cl = c & (lc - 1);
+            for (int part = 0; part < (LC >> sh); ++part) {
+                const bool mine_ = (c >> sh) == part;
+                __syncthreads();                 // the previous part's LDS reads are done
+                // ---- phase 1: the touched beams, four per round (lane group g takes the g-th of them): normalise the
+                //      entry (the energy is in L1 / L2 from the loads above), write it back, stage it if the beam is present
+                if (mine_) {
+                    long hs1 = hsize;            // opaque: keeps the address arithmetic of this phase out of the pair loop's registers
+                    asm volatile("" : "+s"(hs1));
+                    unsigned long long tm = touched;
+                    while (tm != 0ull) {
+                        int bb[LCH];
+                        double E[LCH], X[LCH], Y[LCH], Z[LCH];
 #pragma unroll
-            for (int s = 0; s < GT; ++s) KA[s] = 0.0;
+                        for (int u = 0; u < LCH; ++u) {
+                            int bq[LG];
 #pragma unroll
-            for (int s = 0; s < GT; ++s)
+                            for (int q = 0; q < LG; ++q) {
+                                bq[q] = tm != 0ull ? __ffsll((long long)tm) - 1 : -1;
+                                tm &= tm - 1ull;
+                            }
+                            bb[u] = g == 0 ? bq[0] : (g == 1 ? bq[1] : (g == 2 ? bq[2] : bq[3]));
+                            // the three direction entries are fetched whether this cell's energy entry turns out to be
+                            // zero or not (few are): all four loads of all rounds of the chunk are in flight together
+                            const bool in = bb[u] >= 0 && valid;
+                            const long o = (long)bb[u] * hs1;
+                            E[u] = in ? fI[o] : 0.0;
+                            X[u] = in ? fx[o] : 0.0;
+                            Y[u] = in ? fy[o] : 0.0;
+                            Z[u] = in ? fz[o] : 0.0;
+                        }
 #pragma unroll
-                for (int u = s + 1; u < GT; ++u) {
-                    const double g = pair_gain(A[s], A[u], c.ux, c.uy, c.uz, a.cs, iaw2, pref);
-                    KA[s] += g * A[u].I;
-                    KA[u] -= g * A[s].I;
-                }
-            unsigned long long mb = ma;
-            while (mb != 0ull) {
-                int bid[GT];
-                BeamAtCell B[GT];
-                load_tile(mb, bid, B);
-                double KB[GT];
-#pragma unroll
-                for (int u = 0; u < GT; ++u) KB[u] = 0.0;
-#pragma unroll
-                for (int s = 0; s < GT; ++s)
-#pragma unroll
-                    for (int u = 0; u < GT; ++u) {
-                        const double g = pair_gain(A[s], B[u], c.ux, c.uy, c.uz, a.cs, iaw2, pref);
-                        KA[s] += g * B[u].I;
-                        KB[u] -= g * A[s].I;
+                        for (int u = 0; u < LCH; ++u) {
+                            const int b = bb[u];
+                            const long o = (long)b * hs1;
+                            double I = 0.0;
+                            if (E[u] != 0.0) {
+                                if (a.frozen) {
+                                    if (E[u] > 0.0 && subcritical && (X[u] != 0.0 || Y[u] != 0.0 || Z[u] != 0.0)) I = E[u] / ds_node;
+                                } else {
+                                    const double ax = X[u], ay = Y[u], az = Z[u];
+                                    const double dn = sqrt(ax * ax + ay * ay + az * az);
+                                    X[u] = Y[u] = Z[u] = 0.0;
+                                    if (subcritical && dn > 0.0) {
+                                        if (E[u] > 0.0) I = E[u] / ds_node;
+                                        X[u] = kmag * (ax / dn);
+                                        Y[u] = kmag * (ay / dn);
+                                        Z[u] = kmag * (az / dn);
+                                    }
+                                    fx[o] = X[u]; fy[o] = Y[u]; fz[o] = Z[u];
+                                }
+                                fI[o] = a.consume ? 0.0 : I;
+                            }
+                            if (b >= 0 && ((mask >> b) & 1ull)) {
+                                const int at = (__popcll(mask & ((1ull << b) - 1ull)) << sh) + cl;
+                                const bool here = I > 0.0;   // a beam absent from THIS cell gives and takes nothing
+                                sI[at] = here ? I : 0.0;
+                                sX[at] = here ? X[u] : 0.0;
+                                sY[at] = here ? Y[u] : 0.0;
+                                sZ[at] = here ? Z[u] : 0.0;
+                                sR[at] = 0.0;
+                            }
+                        }
                     }
-#pragma unroll
-                for (int u = 0; u < GT; ++u)
-                    if (bid[u] >= 0 && valid) raw[(long)bid[u] * hsize] += KB[u];
-            }
-#pragma unroll
-            for (int s = 0; s < GT; ++s)
-                if (aid[s] >= 0 && valid) {
-                    const long o = (long)aid[s] * hsize;
-                    // a beam that is absent from THIS cell has K = 0 (its sums above came from whatever its
-                    // entry held); its intensity was masked to zero, so it gave nothing to the others
-                    const double r = A[s].I > 0.0 ? raw[o] + KA[s] : 0.0;
-                    double *gp = a.gain + o + hs;
-                    const double old = *gp;
-                    const double nw = old + a.relax * (r - old);
-                    if (nw != old) *gp = nw;
-                    sum_change += fabs(nw - old);
-                    sum_abs += fabs(nw);
+                    if (n + g < LG * tiles) {    // the padding slots of the last tile
+                        const int at = ((n + g) << sh) + cl;
+                        sI[at] = 0.0; sX[at] = 0.0; sY[at] = 0.0; sZ[at] = 0.0; sR[at] = 0.0;
+                    }
                 }
-        }
-        if (a.consume && valid) {
-            // consume: the energy entries have done their work -- hand them back zeroed, so that the next field pass
-            // can accumulate into them without a memset in between (the lines were just written, they are in L2);
-            // the direction entries stay: later passes reuse them (GainArgs.frozen)
-            unsigned long long mz = mask;
-            while (mz != 0ull) {
-                const long o = (long)(__ffsll((long long)mz) - 1) * hsize;
-                mz &= mz - 1;
-                fI[o] = 0.0;
-            }
-        }
-        if (valid) {  // beams absent from the whole brick relax towards zero
-            unsigned long long rest = ~mask & (a.nbeams >= 64 ? ~0ull : ((1ull << a.nbeams) - 1));
-            while (rest != 0ull) {
-                const int b = __ffsll((long long)rest) - 1;
-                rest &= rest - 1;
-                double *gp = a.gain + (long)b * hsize + hs;
-                const double old = *gp;
-                const double nw = old + a.relax * (0.0 - old);
-                if (nw != old) *gp = nw;
-                sum_change += fabs(nw - old);
-                sum_abs += fabs(nw);
+                __syncthreads();
+                // ---- phase 2: every unordered pair once
+                if (mine_) {
+                    for (int ta = 0; ta < tiles; ++ta) {
+                        // inside the tile: lane group g pairs its own beam g with beams g+1 and (g < 2) g+2, cyclically --
+                        // the six pairs in two evaluations; each lane adds to its own beam's sum and to the partner's,
+                        // and the partners of one instruction are four different beams
+                        {
+                            const int self = ((LG * ta + g) << sh) + cl;
+                            const int p1 = ((LG * ta + ((g + 1) & 3)) << sh) + cl, p2 = ((LG * ta + ((g + 2) & 3)) << sh) + cl;
+                            BeamAtCell S, P1, P2;
+                            S.I = sI[self]; S.kx = sX[self]; S.ky = sY[self]; S.kz = sZ[self];
+                            P1.I = sI[p1]; P1.kx = sX[p1]; P1.ky = sY[p1]; P1.kz = sZ[p1];
+                            P2.I = sI[p2]; P2.kx = sX[p2]; P2.ky = sY[p2]; P2.kz = sZ[p2];
+                            const double g1 = pair_gain_fast(S, P1, ux, uy, uz, a.cs, iaw2, pref_iaw2);
+                            const double g2 = g < 2 ? pair_gain_fast(S, P2, ux, uy, uz, a.cs, iaw2, pref_iaw2) : 0.0;
+                            sR[self] += g1 * P1.I + g2 * P2.I;
+                            lds_order();             // the next statement's entries are other lanes' `self`
+                            sR[p1] -= g1 * S.I;
+                            lds_order();
+                            sR[p2] -= g2 * S.I;
+                            lds_order();
+                        }
+                        if (ta + 1 == tiles) break;
+                        BeamAtCell A[LG];
+                        double KA[LG];
+#pragma unroll
+                        for (int s_ = 0; s_ < LG; ++s_) {
+                            const int at = ((LG * ta + s_) << sh) + cl;
+                            A[s_].I = sI[at]; A[s_].kx = sX[at]; A[s_].ky = sY[at]; A[s_].kz = sZ[at];
+                            KA[s_] = 0.0;
+                        }
+                        for (int tb = ta + 1; tb < tiles; ++tb) {
+                            const int bt = ((LG * tb + g) << sh) + cl;
+                            BeamAtCell B;
+                            B.I = sI[bt]; B.kx = sX[bt]; B.ky = sY[bt]; B.kz = sZ[bt];
+                            double KB = 0.0;
+#pragma unroll
+                            for (int s_ = 0; s_ < LG; ++s_) {
+                                const double gn = pair_gain_fast(A[s_], B, ux, uy, uz, a.cs, iaw2, pref_iaw2);
+                                KA[s_] += gn * B.I;
+                                KB -= gn * A[s_].I;
+                            }
+                            sR[bt] += KB;
+                        }
+                        // fold the four lane groups' partial sums of the A beams; group g keeps beam g's
+                        double fold = 0.0;
+#pragma unroll
+                        for (int s_ = 0; s_ < LG; ++s_) {
+                            double t = KA[s_];
+                            t += __shfl_xor(t, 16, kWave);
+                            t += __shfl_xor(t, 32, kWave);
+                            if (s_ == g) fold = t;
+                        }
+                        sR[((LG * ta + g) << sh) + cl] += fold;
+                    }
+                }
+                __syncthreads();
+                // ---- phase 3: relax the gain of every beam towards its sum (zero where the beam is not in the cell)
+                if (mine_ && valid) {
+                    long hs3 = hsize;
+                    asm volatile("" : "+s"(hs3));
+                    for (int r0 = 0; r0 < rounds; r0 += LCH3) {
+                        double old[LCH3];
+#pragma unroll
+                        for (int u = 0; u < LCH3; ++u) {
+                            const int b = LG * (r0 + u) + g;
+                            old[u] = b < a.nbeams ? a.gain[(long)b * hs3 + hs] : 0.0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < LCH3; ++u) {
+                            const int b = LG * (r0 + u) + g;
+                            if (b >= a.nbeams) continue;
+                            double raw = 0.0;
+                            if ((mask >> b) & 1ull) {
+                                const int at = (__popcll(mask & ((1ull << b) - 1ull)) << sh) + cl;
+                                raw = sI[at] > 0.0 ? sR[at] : 0.0;
+                            }
+                            const double nw = old[u] + a.relax * (raw - old[u]);
+                            if (nw != old[u]) a.gain[(long)b * hs3 + hs] = nw;
+                            sum_change += fabs(nw - old[u]);
+                            sum_abs += fabs(nw);
+                        }
+                    }
+                }
             }
         }
     }
@@ -441,11 +571,15 @@ hipError_t launch_edep_average(const double *edep, double *out, int nx, int ny, 
 hipError_t launch_gain_field(const GainArgs &a, hipStream_t stream)
 {
     if (a.hx_hi <= a.hx_lo) return hipSuccess;
+    if (a.scratch) {                       // one single-wavefront workgroup per z-row of the slab
+        const long rows = (long)(a.hx_hi - a.hx_lo) * (a.ny + 2);
+        hipLaunchKernelGGL(k_gain_field_sym, dim3((unsigned)rows), dim3(64), 0, stream, a);
+        return hipGetLastError();
+    }
     const long bricks = (long)(((a.hx_hi + 1) >> 1) - (a.hx_lo >> 1)) * ((a.ny + 5) / 4) * ((a.nz + 9) / 8);  // 2 x 4 x 8 cells of the haloed grid each
     long blocks = (bricks + 3) / 4;                                                    // four wavefronts per workgroup
     if (blocks > 256 * 64) blocks = 256 * 64;
-    if (a.scratch) hipLaunchKernelGGL(k_gain_field_sym, dim3((unsigned)blocks), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(k_gain_field, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(k_gain_field, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -127,12 +127,18 @@ class RayTracer:
         """Zeroed [4][nbeams][(n+2)^3] field array (energy x path length, energy x displacement x/y/z)."""
         return torch.zeros((4, self.params.nbeams) + self.grid_shape, dtype=torch.float64, device=self.device)
 
-    def gain_field(self, fields, gain, gain_params, change=None, ne3d=None, scratch=None, x_lo=0, x_hi=None, frozen=False):
+    def gain_field(self, fields, gain, gain_params, change=None, ne3d=None, scratch=None, x_lo=0, x_hi=None, frozen=False,
+                   pair_once=None):
         """Normalise `fields` in place and relax `gain` towards the gain coefficient they imply.
-        scratch: a work array shaped like `gain` (each beam pair evaluated once), or None (ordered kernel).
+        pair_once: the kernel that evaluates each beam pair once, the cell's beams staged in LDS (True), or the ordered
+        kernel in the CPU checker's sum order (False).  `scratch` is the C ABI's selector for the same choice (any
+        tensor = pair-once; it is not touched) and is kept for callers of the earlier signature.
         x_lo, x_hi: only the planes [x_lo, x_hi) of the deposit grid (one rank's slab).
         frozen: fields[1:4] already hold k from an earlier call; only fields[0] is read and normalised."""
         stream = torch.cuda.current_stream(self.device).cuda_stream
+        if pair_once is None:
+            pair_once = scratch is not None
+        scratch = gain if pair_once else None
         api.gain_field_slab(fields, ne3d, gain, scratch, change, x_lo, self.grid_shape[0] if x_hi is None else x_hi,
                             self.params, _frozen(gain_params, frozen), self.ctx, stream)
         return gain
@@ -363,7 +369,6 @@ class _DeviceCbetEngine:
         tr = self.tr
         self.fields = tr.new_fields() if self._fields is None else self._fields
         self.gain = tr.new_grid(per_beam=True) if self._gain is None else self._gain
-        self.scratch = torch.empty_like(self.gain)
         tr.tabulate()
         self.gain.zero_()
 
@@ -376,7 +381,7 @@ class _DeviceCbetEngine:
 
     def update_gain(self, fields, frozen=False):
         self.change.zero_()
-        self.tr.gain_field(fields, self.gain, self.gp, self.change, scratch=self.scratch, frozen=frozen)
+        self.tr.gain_field(fields, self.gain, self.gp, self.change, pair_once=True, frozen=frozen)
         return self.change
 
     def deposit(self, shard_index, shard_count):
@@ -395,14 +400,13 @@ class _DeviceCbetEngine:
         self.gain_own = torch.zeros((b1 - b0,) + gs, **f64)
         self.slab_fields = torch.zeros((4, nb, x1 - x0) + gs[1:], **f64)
         self.gain_slab = torch.zeros((nb, x1 - x0) + gs[1:], **f64)
-        self.scratch_slab = torch.empty((nb, x1 - x0) + gs[1:], **f64)
         self.gain = self.gain_own            # what a caller gets back: this rank's beams over the whole grid
         tr.tabulate()
 
     def slab_bytes(self):
         """Device bytes this rank's slab loop holds: the arrays of begin_slabs, the exchange's two staging buffers and
         (sparse exchanges) the segment lists."""
-        arrays = 8 * sum(t.numel() for t in (self.own_fields, self.gain_own, self.slab_fields, self.gain_slab, self.scratch_slab))
+        arrays = 8 * sum(t.numel() for t in (self.own_fields, self.gain_own, self.slab_fields, self.gain_slab))
         xch = getattr(self, "exchanger", None)
         if xch is None:
             return arrays
@@ -442,7 +446,7 @@ class _DeviceCbetEngine:
         self.change.zero_()
         if self.x1 > self.x0:
             stream = torch.cuda.current_stream(self.tr.device).cuda_stream
-            api.gain_field_packed(self.slab_fields, None, self.gain_slab, self.scratch_slab, self.change, self.x0, self.x1,
+            api.gain_field_packed(self.slab_fields, None, self.gain_slab, self.gain_slab, self.change, self.x0, self.x1,
                                   self.tr.params, _frozen(self.gp, frozen), self.tr.ctx, stream)
         return self.change
 
@@ -786,7 +790,7 @@ def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_s
     Rank r traces WHOLE beams [b_r0, b_r1) -- their four fields are complete on r without any reduction -- and
     owns the x-slab [x_r0, x_r1) of the deposit grid for the gain update.  It STORES only
         its own beams over the whole grid : own_fields [4][nb_r][X][Y][Z], gain_own [nb_r][X][Y][Z]
-        all beams over its own slab       : slab_fields [4][nb][x_r][Y][Z], gain_slab and scratch [nb][x_r][Y][Z]
+        all beams over its own slab       : slab_fields [4][nb][x_r][Y][Z], gain_slab [nb][x_r][Y][Z]
     i.e. (5 nb_r + 6 nb / W) grids instead of 6 nb: 92 GB per rank at 512^3 / 60 beams / 8 ranks against 391 GB
     (cbet_cbet_slab_workspace_bytes).  Per pass: (1) every rank sends each slab owner its beams' fields over that
     slab (all-to-all, (W-1)/W of own_fields); (2) each rank updates the gain of ALL beams on its slab; (3) it sends

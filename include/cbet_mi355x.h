@@ -352,10 +352,11 @@ int cbet_trace_cbet(int b, unsigned nindices, const double *ne3d, const double *
  * energy is not positive); with g->directions_frozen the k entries are taken as they are and only the energy
  * entries are read and normalised.  gain: device [nbeams][(n+2)^3], updated to
  * gain + relax (K - gain).  change: device double[2], ADDED into: {sum |new - old|, sum |new|}
- * (may be NULL).  scratch: device [nbeams][(n+2)^3] work array (contents ignored and overwritten) --
- * with it every unordered beam pair is evaluated once; NULL selects the ordered kernel (twice the
- * pair evaluations, no extra memory; K equal to the last bits).  ne3d NULL = the context's node table.
- * Needs nbeams <= CBET_MAX_CBET_BEAMS.
+ * (may be NULL).  scratch: a SELECTOR, kept in the signature for ABI stability: any non-NULL pointer selects
+ * the kernel that evaluates every unordered beam pair once with the cell's beams staged in LDS (it is never
+ * dereferenced since round 3 -- pass `gain`); NULL selects the ordered kernel (twice the pair evaluations, every
+ * statement one IEEE operation in the CPU checker's order; the pair-once kernel's K agrees with it to ~1e-13
+ * of the largest |K|).  ne3d NULL = the context's node table.  Needs nbeams <= CBET_MAX_CBET_BEAMS.
  */
 int cbet_gain_field(double *fields, const double *ne3d, double *gain, double *scratch, double *change,
                     const cbet_params *p, const cbet_gain_params *g, cbet_context *ctx, void *stream);
@@ -368,7 +369,7 @@ int cbet_gain_field_slab(double *fields, const double *ne3d, double *gain, doubl
                          int hx_lo, int hx_hi, const cbet_params *p, const cbet_gain_params *g,
                          cbet_context *ctx, void *stream);
 /*
- * cbet_gain_field_slab on SLAB-PACKED arrays: fields [4][nbeams][slab], gain and scratch [nbeams][slab] hold only
+ * cbet_gain_field_slab on SLAB-PACKED arrays: fields [4][nbeams][slab] and gain [nbeams][slab] hold only
  * the planes [hx_lo, hx_hi) of every beam's haloed grid (slab = (hx_hi - hx_lo)(ny+2)(nz+2) doubles per beam and
  * component) -- what one rank of the slab-owned loop stores: all beams over its own x-slab.
  */
@@ -388,14 +389,14 @@ int cbet_unpack_segments(double *dst, long beam_stride, int hy, int hz, const in
                          void *stream);
 /*
  * Device bytes one rank of the slab-owned CBET loop (tracer.cbet_fixed_point_slabs) needs beside the node tables:
- * its own beams' four field components and gain over the whole grid, all beams' fields, gain and scratch over
+ * its own beams' four field components and gain over the whole grid, all beams' fields and gain over
  * its x-slab, and (world_size > 1) the two staging buffers of the chunked all-to-all exchanges -- one peer and one
  * field component at a time: ceil(nbeams / W) x ceil((nx+2) / W) x (ny+2)(nz+2) doubles each.  0 on bad arguments.
  * (512^3, 60 beams, 8 ranks: ~95 GB per rank, 2.2 GB of it staging; every rank holding everything,
  * cbet_cbet_workspace_bytes, would be 391 GB.)
  */
 size_t cbet_cbet_slab_workspace_bytes(const cbet_params *p, int world_size, int rank);
-/* Bytes of device workspace cbet_cbet_solve needs: 6 nbeams (n+2)^3 doubles + a few scalars. */
+/* Bytes of device workspace cbet_cbet_solve needs: 5 nbeams (n+2)^3 doubles (four field components + gain) + a few scalars. */
 size_t cbet_cbet_workspace_bytes(const cbet_params *p);
 /*
  * The whole iteration on the current device: tabulate the plasma; repeat { field pass with the

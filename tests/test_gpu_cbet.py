@@ -111,7 +111,7 @@ def test_field_pass_matches_oracle(api, setup, torch_cuda):
 @pytest.mark.parametrize("symmetric", [False, True])
 def test_gain_field_matches_oracle_and_is_antisymmetric(api, oracle, setup, torch_cuda, symmetric):
     """Both gain kernels: the ordered one (the oracle's sum order) and the one that evaluates every
-    unordered pair once into a scratch array (sums grouped by beam tile)."""
+    unordered pair once with the cell's beams staged in LDS (sums grouped by beam tile, pair function as one quotient)."""
     tr, gp = setup["tr"], setup["gp"]
     fields = torch_cuda.from_numpy(setup["ofields"].copy()).cuda()
     gain = tr.new_grid(per_beam=True)
@@ -150,6 +150,56 @@ def test_gain_field_matches_oracle_and_is_antisymmetric(api, oracle, setup, torc
     fields2 = torch_cuda.from_numpy(setup["ofields"].copy()).cuda()
     tr.gain_field(fields2, gain2, api.default_gain_params(relax=0.25), None, scratch=scratch)
     assert np.abs(gain2.cpu().numpy() - 0.25 * K).max() < 1e-12 * scale
+
+
+def test_pair_once_kernel_on_crowded_cells_equals_the_ordered_kernel(api, inputs, torch_cuda):
+    """The pair-once kernel stages a 16-cell z-run's present beams in 20 LDS slots and takes a run crossed by more beams in
+    halves (<= 40) or quarters (<= 64): synthetic fields of all 60 beams whose crowding grows along x -- ~9, ~30 and ~54
+    beams per cell, entries that are touched but not present (E < 0), untouched ones (E = 0), a ragged last z-run
+    (nz + 2 = 18 cells: a full run and a run of two) -- must give the ordered kernel's K, and the same normalised fields, first call and frozen."""
+    from cbet_raytracing_3d_amd.tracer import RayTracer
+    torch = torch_cuda
+    bn, r, ne, te = inputs
+    n = 16
+    tr = RayTracer(api.default_params(n, nbeams=60), r, ne, te)
+    tr.tabulate()
+    gen = torch.Generator(device="cuda").manual_seed(20261004)
+    shape = (60,) + tr.grid_shape
+    u = torch.rand(shape, generator=gen, device="cuda", dtype=torch.float64)
+    row = torch.rand(shape[:3] + (1,), generator=gen, device="cuda", dtype=torch.float64)   # a beam crosses a z-row or not
+    x = torch.arange(tr.grid_shape[0], device="cuda").view(1, -1, 1, 1)
+    density = torch.where(x < 5, 0.15, torch.where(x < 10, 0.45, 0.9)).to(torch.float64)
+    present = (row < density) & (u < 0.8)
+    touched_only = (row < density + 0.03) & ~present & (u < 0.9)
+    raw = torch.zeros((4,) + shape, dtype=torch.float64, device="cuda")
+    e = torch.rand(shape, generator=gen, device="cuda", dtype=torch.float64) * 1e3 + 1.0
+    raw[0] = torch.where(present, e, torch.where(touched_only, -e, torch.zeros_like(e)))
+    raw[1:] = (torch.rand((3,) + shape, generator=gen, device="cuda", dtype=torch.float64) - 0.5) * (raw[0] != 0)
+    crowd = torch.stack([present[..., :16].any(-1).sum(0), present[..., 16:].any(-1).sum(0)])   # beams per z-run
+    assert int((crowd <= 20).sum()) > 50 and int(((crowd > 20) & (crowd <= 40)).sum()) > 50 and int((crowd > 40).sum()) > 50
+    gp = api.default_gain_params(relax=1.0)
+    results = {}
+    for pair_once in (False, True):
+        f = raw.clone()
+        k = tr.new_grid(per_beam=True)
+        ch = torch.zeros(2, dtype=torch.float64, device="cuda")
+        tr.gain_field(f, k, gp, ch, pair_once=pair_once)
+        f2 = f.clone()
+        f2[0] = raw[0]
+        k2 = torch.zeros_like(k)
+        tr.gain_field(f2, k2, gp, None, pair_once=pair_once, frozen=True)
+        results[pair_once] = (f.cpu().numpy(), k.cpu().numpy(), ch.cpu().numpy(), f2.cpu().numpy(), k2.cpu().numpy())
+    (f_o, k_o, ch_o, f2_o, k2_o), (f_p, k_p, ch_p, f2_p, k2_p) = results[False], results[True]
+    scale = np.abs(k_o).max()
+    assert scale > 0
+    assert np.array_equal(f_p, f_o) and np.array_equal(f2_p, f2_o)          # the normalisation is the same arithmetic
+    assert np.abs(k_p - k_o).max() < 1e-12 * scale
+    assert np.abs(k2_p - k_o).max() < 1e-12 * scale and np.abs(k2_o - k_o).max() < 1e-12 * scale
+    assert abs(ch_p[1] / ch_o[1] - 1.0) < 1e-12 and abs(ch_p[0] / ch_o[0] - 1.0) < 1e-12
+    # exchange in a cell sums to zero, crowded or not
+    inten = np.where(f_p[0] > 0, f_p[0], 0.0)
+    assert np.abs((inten * k_p).sum(axis=0)).max() <= 1e-11 * np.abs(inten * k_p).sum(axis=0).max()
+    tr.close()
 
 
 def test_gain_pass_matches_oracle(api, oracle, setup, torch_cuda):
