@@ -1,9 +1,10 @@
 // cbet_grid_kernels.hip -- the cell-parallel kernels beside the ray integrator (cbet_kernels.hip):
-//   * k_gain_field, k_gain_field_sym : per-beam fields -> CBET gain coefficient (no
+//   * k_gain_field (ordered), k_gain_field_sym (pairs once, LDS-staged) : per-beam fields -> CBET gain coefficient (no
 //     reference counterpart, parity unpinned -- model and layout in DESIGN.md section 9)
 //   * k_edep_average                 : the 27-point node average of main.cu:334-349
-// Built with -ffp-contract=off like the rest of the library: every statement below is one IEEE
-// operation in the order written, which is the order the CPU checker of the CBET stage uses.
+// Built with -ffp-contract=off like the rest of the library: every statement of the ordered kernel and of the
+// normalisation is one IEEE operation in the order written, which is the order the CPU checker of the CBET stage
+// uses; the pair-once kernel's pair function (pair_gain_fast) is the exception and says so.
 #include <hip/hip_runtime.h>
 
 #include "cbet_device.h"
@@ -185,14 +186,15 @@ struct BeamAtCell {
 // (cell_state: two square roots, five divisions) is computed for 64 cells at a time and handed out by lane shuffles.
 // The sums live in LDS: GainArgs.scratch only selects this kernel, it is never dereferenced.
 //
-// Measured (round 3, 256^3, 60 beams, frozen directions; profiles/r3/cbet_gain/): 11.5 ms against 19.2 ms for the kernel
-// it replaces (tiles re-streamed from memory, sums in a scratch array: 108 GB fetched + 14 GB written per call, every
-// B tile of a brick's ~41 KB missing L1 and L2); 46 GB fetched + 5.6 GB written, SQ_INSTS_VALU 3.6e9 at 61 % of the
-// vector issue rate.  What was tried on the way (profiles/r3/experiments/gain_kernel.log): the whole grid's 4 waves per
-// CU with 64 slots (27.9 ms), exact IEEE pair function (12.5 ms at the same occupancy), masks by ballots and scalar bit
-// tests (+530 SALU per run, 11.8 -> 11.4 ms when replaced), LDS-DMA prefetch of the next run's lines (13.4 ms), LCAP
-// 16 / 24 / 28 / 32 (13.0 / 12.0 / 13.2 / 13.4 ms), an XCD-contiguous brick order for the old kernel (23.2 ms: the
-// central slabs are the heavy ones) and 2x2x16 / 1x4x16 bricks for it (20.6 / 26 ms).
+// Measured (round 3, 256^3, 60 beams, frozen directions; profiles/r3/cbet/): 11.0-11.4 ms against 19.2 ms for the kernel
+// it replaces (one wavefront per 2x4x8 brick, B tiles re-streamed from memory, sums in a scratch array: 108 GB fetched +
+// 14 GB written per call, 70 % of its 1.3e9 line requests missing L2); now 46 GB fetched + 5.3 GB written,
+// SQ_INSTS_VALU 3.7e9 = 0.55 of the vector issue rate.  The steps in between (profiles/r3/experiments/gain_kernel.log):
+// 64 slots and 4 waves per CU 27.9 ms; 32 slots / 8 waves with the exact IEEE pair function 22.8; the pair function as
+// one quotient, in-tile pairs in two evaluations, phase 1 over touched beams only 14.4 (20 slots: 12.5); masks by
+// transposition instead of ballots + 530 scalar bit tests per run, plasma state per 64 cells 11.8; all of phase 1's
+// loads in flight 11.4.  LCAP 16 / 24 / 28 / 32: 13.0 / 12.0 / 13.2 / 13.4 ms; LDS-DMA prefetch of the next run's
+// lines 13.4 ms.
 // ---------------------------------------------------------------------------------------------
 constexpr int LC = 16, LG = 4, LCAP = 20, LROUNDS = 64 / LG;
 constexpr int LCH = 4, LCH3 = 8;   // rounds whose loads are in flight together in phase 1 / phase 3
@@ -201,7 +203,7 @@ constexpr int LCH = 4, LCH3 = 8;   // rounds whose loads are in flight together 
 //   P = iaw^2 eta / ((eta^2 - 1)^2 + iaw^2 eta^2) = iaw^2 N D^3 / ((N^2 - D^2)^2 + iaw^2 N^2 D^2),
 // square root and reciprocal by the hardware estimates and Newton steps (a few ulp; the sums of the symmetric kernels are
 // grouped differently from the ordered kernel's anyway).  q = 0 (a beam against itself, or two parallel beams) gives
-// N = 0 over D^4 = 1e-40: zero, as in pair_gain.
+// N = 0 over D^4 = 1e-40: zero, as in the ordered kernel.
 __device__ __forceinline__ double pair_gain_fast(const BeamAtCell &bi, const BeamAtCell &bj, double ux, double uy, double uz,
                                                  double cs, double iaw2, double pref_iaw2)
 {

@@ -10,7 +10,8 @@ for f in ("bench_default.json", "bench_n100.json", "bench_n512.json", "bench_n51
           "shard_timing.log", "launch_size_curve.log"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
-shutil.copy(os.path.join(src, "pmc", "summary.txt"), os.path.join(dst, "pmc", "summary.txt"))
+if os.path.exists(os.path.join(src, "pmc", "summary.txt")):
+    shutil.copy(os.path.join(src, "pmc", "summary.txt"), os.path.join(dst, "pmc", "summary.txt"))
 if os.path.exists(os.path.join(src, "cbet", "kernel_stats.csv")):
     shutil.copy(os.path.join(src, "cbet", "kernel_stats.csv"), os.path.join(dst, "cbet", "kernel_stats.csv"))
     with open(os.path.join(dst, "cbet", "cbet_profile.log"), "w") as fo:
@@ -21,6 +22,27 @@ if os.path.exists(os.path.join(src, "cbet", "kernel_stats.csv")):
 
 if os.path.exists(os.path.join(src, "cbet_pmc", "summary.txt")):
     shutil.copy(os.path.join(src, "cbet_pmc", "summary.txt"), os.path.join(dst, "cbet", "pmc_summary.txt"))
+    # cbet/traffic.json: the per-launch counts bench.py prices the CBET iteration's two kernels with
+    per = collections.defaultdict(dict)
+    for line in open(os.path.join(src, "cbet_pmc", "summary.txt")):
+        head, rest = line.rsplit(" n=", 1)
+        kernel, counter = head.rsplit(" ", 1)
+        per[kernel][counter] = float(rest.split("mean=")[1].split()[0])
+    note = ("%s/cbet/pmc_summary.txt: separate rocprofv3 --pmc passes of scripts/cbet_gain_pmc.sh on scripts/cbet_scale.py 256 60 "
+            "(mean over the kernel's dispatches of the run: the direct calls + those of the solve); hbm = (2 x FETCH_SIZE + "
+            "WRITE_SIZE) * 1024 B (FETCH_SIZE tallies 128-B requests at 64 B on gfx950)" % dst)
+    cb = []
+    for kernel, m in per.items():
+        if "FETCH_SIZE" not in m or "SQ_INSTS_VALU" not in m:
+            continue
+        cb.append({"kernel": kernel, "SQ_INSTS_SALU_per_launch": m.get("SQ_INSTS_SALU"), "SQ_INSTS_VALU_per_launch": m["SQ_INSTS_VALU"],
+                   "SQ_INSTS_LDS_per_launch": m.get("SQ_INSTS_LDS"),
+                   "SQ_WAIT_ANY_per_launch": m.get("SQ_WAIT_ANY"), "SQ_WAVE_CYCLES_per_launch": m.get("SQ_WAVE_CYCLES"),
+                   "TCC_EA0_ATOMIC_sum_per_launch": m.get("TCC_EA0_ATOMIC_sum"), "TCC_HIT_sum_per_launch": m.get("TCC_HIT_sum"),
+                   "TCC_MISS_sum_per_launch": m.get("TCC_MISS_sum"), "FETCH_SIZE_KiB": m["FETCH_SIZE"], "WRITE_SIZE_KiB": m["WRITE_SIZE"],
+                   "hbm_bytes_per_launch": (2.0 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024.0, "source": note})
+    json.dump({"workload": "omega60_256cube_s83177_absorption + CBET fixed-point iteration", "entries": cb},
+              open(os.path.join(dst, "cbet", "traffic.json"), "w"), indent=1)
 if os.path.exists(os.path.join(src, "cbet_rank_share.log")):
     shutil.copy(os.path.join(src, "cbet_rank_share.log"), os.path.join(dst, "cbet_rank_share.log"))
 
@@ -50,6 +72,8 @@ for p in range(1, 16):
             if k.startswith("k_trace_window"):
                 means[c] = (sum(v) / len(v), "pmc/pass%d.csv" % p)
 
+if not means:      # a CBET-only refresh: the trace kernel's counter profile stays as it is
+    sys.exit(0)
 bench = json.load(open(os.path.join(dst, "bench_default.json")))
 rl = bench["roofline"]
 wave_steps = bench["config"]["ray_steps_per_pass"] / 64.0 / rl["lane_utilisation"]

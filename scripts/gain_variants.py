@@ -22,7 +22,7 @@ if len(sys.argv) > 3:
     cells = pres.sum(0).flatten().float()
     print("beams present per cell: mean %.1f, mean over cells with any %.1f, max %d; sum n^2 weighted mean %.1f"
           % (cells.mean(), cells[cells > 0].mean(), int(cells.max()), float((cells ** 3).sum() / (cells ** 2).sum())))
-    for (sx, sy, sz) in ((2, 4, 8), (2, 2, 16), (1, 4, 16)):
+    for (sx, sy, sz) in ((1, 1, 16), (2, 4, 8)):
         px, py, pz = (-X) % sx, (-Y) % sy, (-Z) % sz
         p = torch.nn.functional.pad(pres, (0, pz, 0, py, 0, px))
         b = p.view(nb, (X + px) // sx, sx, (Y + py) // sy, sy, (Z + pz) // sz, sz).amax((2, 4, 6)).sum(0).flatten().float()
