@@ -194,7 +194,8 @@ struct BeamAtCell {
 // one quotient, in-tile pairs in two evaluations, phase 1 over touched beams only 14.4 (20 slots: 12.5); masks by
 // transposition instead of ballots + 530 scalar bit tests per run, plasma state per 64 cells 11.8; all of phase 1's
 // loads in flight 11.4.  LCAP 16 / 24 / 28 / 32: 13.0 / 12.0 / 13.2 / 13.4 ms; LDS-DMA prefetch of the next run's
-// lines 13.4 ms.
+// lines 13.4 ms; FROZEN as a template parameter 11.5 -> 11.1; skipping phase-3 rounds whose four beams are absent and
+// carry no gain: nothing.
 // ---------------------------------------------------------------------------------------------
 constexpr int LC = 16, LG = 4, LCAP = 20, LROUNDS = 64 / LG;
 constexpr int LCH = 4, LCH3 = 8;   // rounds whose loads are in flight together in phase 1 / phase 3
@@ -235,6 +236,7 @@ __device__ __forceinline__ void lds_order()
     __builtin_amdgcn_wave_barrier();
 }
 
+template <bool FROZEN>
 __global__ void __launch_bounds__(64, 3) k_gain_field_sym(const GainArgs a)
 {
     static_assert(5 * LCAP * LC >= 64 * (LC + 1), "the slot arrays double as the staging area of the presence masks");
@@ -335,7 +337,7 @@ __global__ void __launch_bounds__(64, 3) k_gain_field_sym(const GainArgs a)
                             const long o = (long)b * hs1;
                             double I = 0.0;
                             if (E[u] != 0.0) {
-                                if (a.frozen) {
+                                if (FROZEN) {
                                     if (E[u] > 0.0 && subcritical && (X[u] != 0.0 || Y[u] != 0.0 || Z[u] != 0.0)) I = E[u] / ds_node;
                                 } else {
                                     const double ax = X[u], ay = Y[u], az = Z[u];
@@ -575,7 +577,8 @@ hipError_t launch_gain_field(const GainArgs &a, hipStream_t stream)
     if (a.hx_hi <= a.hx_lo) return hipSuccess;
     if (a.scratch) {                       // one single-wavefront workgroup per z-row of the slab
         const long rows = (long)(a.hx_hi - a.hx_lo) * (a.ny + 2);
-        hipLaunchKernelGGL(k_gain_field_sym, dim3((unsigned)rows), dim3(64), 0, stream, a);
+        if (a.frozen) hipLaunchKernelGGL(k_gain_field_sym<true>, dim3((unsigned)rows), dim3(64), 0, stream, a);
+        else hipLaunchKernelGGL(k_gain_field_sym<false>, dim3((unsigned)rows), dim3(64), 0, stream, a);
         return hipGetLastError();
     }
     const long bricks = (long)(((a.hx_hi + 1) >> 1) - (a.hx_lo >> 1)) * ((a.ny + 5) / 4) * ((a.nz + 9) / 8);  // 2 x 4 x 8 cells of the haloed grid each
