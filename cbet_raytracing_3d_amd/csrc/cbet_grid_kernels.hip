@@ -195,7 +195,10 @@ struct BeamAtCell {
 // transposition instead of ballots + 530 scalar bit tests per run, plasma state per 64 cells 11.8; all of phase 1's
 // loads in flight 11.4.  LCAP 16 / 24 / 28 / 32: 13.0 / 12.0 / 13.2 / 13.4 ms; LDS-DMA prefetch of the next run's
 // lines 13.4 ms; FROZEN as a template parameter 11.5 -> 11.1; skipping phase-3 rounds whose four beams are absent and
-// carry no gain: nothing.
+// carry no gain: nothing.  Where the 11.2 ms go (timing builds that skip phases): masks 2.3, phase 1 2.5, phase 2 4.0,
+// phase 3 2.6 -- additive: a wavefront's phases do not overlap with each other, only with other wavefronts'.  Whole-line
+// z-rows (grids with nz + 2 a multiple of 16: 270^3) are ~8 % faster per cell, not more: the memory phases wait on
+// latency at 12 waves per CU, not on bytes.
 // ---------------------------------------------------------------------------------------------
 constexpr int LC = 16, LG = 4, LCAP = 20, LROUNDS = 64 / LG;
 constexpr int LCH = 4, LCH3 = 8;   // rounds whose loads are in flight together in phase 1 / phase 3

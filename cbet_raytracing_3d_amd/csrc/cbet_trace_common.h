@@ -226,6 +226,20 @@ __device__ __forceinline__ double phi_small(double x)
     return p;
 }
 
+// sqrt of a positive normal number far from the ends of the exponent range (a squared speed, cm^2/s^2), within an ulp:
+// reciprocal-square-root estimate, one Goldschmidt step, two corrections -- without the range scaling and the special
+// cases of the library sqrt (13 instructions for 27).  CBET extension only (the path length of a step); the reference
+// path has no square root in its step.
+__device__ __forceinline__ double sqrt_speed(double v2)
+{
+    const double r0 = __builtin_amdgcn_rsq(v2);
+    double g = v2 * r0, h = 0.5 * r0;
+    const double e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g); h = __builtin_fma(h, e, h);
+    g = __builtin_fma(__builtin_fma(-g, g, v2), h, g);
+    return __builtin_fma(__builtin_fma(-g, g, v2), h, g);
+}
+
 // The work item of workgroup `w` of a launch: which (beam, patch) bundle.  The list is beam-major -- consecutive
 // workgroups are neighbouring patches of one beam and share table lines in L2/MALL -- with each beam's patches
 // longest rays first (a globally longest-first order and a patch-major order were measured 9-17 % slower).  A

@@ -672,7 +672,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
             const double wgt[8] = {zy00 * Fx0, zy00 * Fx1, zy10 * Fx0, zy10 * Fx1, zy01 * Fx0, zy01 * Fx1, zy11 * Fx0, zy11 * Fx1};
             // path length of the step; u_eff = the ray's energy averaged over the step
             double ds = 0.0;
-            if (gk || CBET >= 2) ds = sqrt(s.vx * s.vx + s.vy * s.vy + s.vz * s.vz) * a.dt;
+            if (gk || CBET >= 2) ds = sqrt_speed(s.vx * s.vx + s.vy * s.vy + s.vz * s.vz) * a.dt;
             double u_eff = s.uray;
             if (gk) {
                 // K at the eight deposit nodes, weighted like the deposit.  The pairwise tree makes the
