@@ -120,7 +120,7 @@ def cbet_leg(api, tr, edep, n):
                 "gain_kernel": priced(prof.get("gain"), t_gain, {
                     "kernel": "k_gain_field_sym", "algorithmic_bytes": alg_gain, "algorithmic_GBps": alg_gain / t_gain / 1e9,
                     "note": "every entry is read once, the cell's beams are staged in LDS (DESIGN.md section 9); measured traffic is "
-                            "~1.25x the workspace (z-runs of 16 cells straddle 128-byte lines: the row pitch is nz+2 doubles); "
+                            "~1.3x the workspace (z-runs of 16 cells straddle 128-byte lines: the row pitch is nz+2 doubles); "
                             "frac = (2 x FETCH_SIZE + WRITE_SIZE) / kernel time / 8 TB/s; the kernel is vector-issue bound "
                             "(valu_issue_frac), not HBM bound"}),
                 "energy_field_pass": priced(prof.get("field"), t_field, {"kernel": "k_trace_window<16,false,2>"}),
