@@ -54,7 +54,10 @@ struct Tile {
     // bank pairs, +2 per lane sharing a bank, +3 per lane sharing an address (scripts/ubench/lds_atomic.hip),
     // and a bundle's footprint is a few nodes wide per axis, so rows are padded by one entry and planes by four
     // (the conflict-free pair (18, 149) for WZ = 16 measured no faster: its extra 576 bytes cost occupancy; the
-    // smaller (17, 136) and (16, 132) are 0.5 ms slower).
+    // smaller (17, 136) and (16, 132) are 0.5 ms slower.  Round 3 scored every pair with the measured cost law on
+    // oracle ray paths, scripts/deposit_layouts.py --pads: nothing with XS <= 144 -- what 14 waves per CU leave --
+    // beats (17, 140); (19, 151) and (19, 153) save 14-15 % of the add cycles in the model and measure 18.4 ms
+    // against 18.3 at 13 waves per CU.)
     // PAD = false: the dense layout, for the rarely used second box.
     static constexpr int YS = PAD ? WZ + 1 : WZ;
     static constexpr int XS = PAD ? WY * YS + 4 : WY * WZ;

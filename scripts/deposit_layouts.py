@@ -21,6 +21,7 @@ from oracle import cbet_oracle as O  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=256)
 ap.add_argument("--bundles", type=int, default=10)
+ap.add_argument("--pads", default="", help="extra padded layouts to score: XS/YS pairs, e.g. 141/17,143/18")
 args = ap.parse_args()
 CB = 2.0
 bn, r, ne, te = load_inputs()
@@ -72,6 +73,14 @@ LAYOUTS = {
     "dense (no swizzle)": lambda X, Y, Z: (Z & 15),
     "ideal (all distinct banks)": None,
 }
+
+
+for _pair in [q for q in args.pads.split(",") if q]:
+    _xs, _ys = (int(v) for v in _pair.split("/"))
+    assert _xs >= 7 * _ys + 16, "rows overlap"
+    LAYOUTS["pad %d/%d" % (_xs, _ys)] = (lambda xs, ys: (lambda X, Y, Z: ((X & 7) * xs + (Y & 7) * ys + (Z & 15)) & 15))(_xs, _ys)
+if args.pads:
+    MAPPINGS = {k: v for k, v in MAPPINGS.items() if "shipped" in k}
 
 
 def bundle_instructions(beam, bx, by, xy, code):
