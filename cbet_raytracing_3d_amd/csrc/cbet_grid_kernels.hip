@@ -186,9 +186,9 @@ struct BeamAtCell {
 // (cell_state: two square roots, five divisions) is computed for 64 cells at a time and handed out by lane shuffles.
 // The sums live in LDS: GainArgs.scratch only selects this kernel, it is never dereferenced.
 //
-// Measured (round 3, 256^3, 60 beams, frozen directions; profiles/r3/cbet/): 11.0-11.4 ms against 19.2 ms for the kernel
+// Measured (round 3, 256^3, 60 beams, frozen directions; profiles/r3/cbet/): 10.9-11.4 ms against 19.2 ms for the kernel
 // it replaces (one wavefront per 2x4x8 brick, B tiles re-streamed from memory, sums in a scratch array: 108 GB fetched +
-// 14 GB written per call, 70 % of its 1.3e9 line requests missing L2); now 50 GB fetched + 5.3 GB written,
+// 14 GB written per call, 70 % of its 1.3e9 line requests missing L2); now ~49 GB fetched + 5.2 GB written,
 // SQ_INSTS_VALU 3.7e9 = 0.55 of the vector issue rate.  The steps in between (profiles/r3/experiments/gain_kernel.log):
 // 64 slots and 4 waves per CU 27.9 ms; 32 slots / 8 waves with the exact IEEE pair function 22.8; the pair function as
 // one quotient, in-tile pairs in two evaluations, phase 1 over touched beams only 14.4 (20 slots: 12.5); masks by
