@@ -355,7 +355,7 @@ class SweepPipeline:
 class _DeviceCbetEngine:
     """The per-rank compute of the CBET iteration on a RayTracer's device (see cbet_fixed_point and
     cbet_fixed_point_slabs).  The all-reduce loop keeps every beam's arrays over the whole grid
-    (cbet_cbet_workspace_bytes: 49.5 GB at 256^3 / 60 beams); the slab-owned loop allocates, in begin_slabs, only
+    (cbet_cbet_workspace_bytes: 41.2 GB at 256^3 / 60 beams); the slab-owned loop allocates, in begin_slabs, only
     its own beams over the whole grid and all beams over its own x-slab (cbet_cbet_slab_workspace_bytes)."""
 
     def __init__(self, tracer, edep, gain_params, fields=None, gain=None):
