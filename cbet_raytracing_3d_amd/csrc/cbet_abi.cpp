@@ -69,6 +69,8 @@ static int validate(const cbet_params *p)
     if (p->max_threads < 1 || p->threads_per_block < 1) return fail(CBET_EINVAL, "bad launch-shape rule");
     if (p->shard_count > 1 && (p->shard_index < 0 || p->shard_index >= p->shard_count))
         return fail(CBET_EINVAL, "shard_index outside [0, shard_count)");
+    if (p->rim_merge != 0 && (p->rim_merge < 8 || p->rim_merge > 64))
+        return fail(CBET_EINVAL, "rim_merge must be 0 (off) or a footprint of 8 .. 64 rays");
     return CBET_OK;
 }
 
@@ -174,25 +176,69 @@ static void build_live_list(const cbet_params *p, const cbet_derived *d, int nin
     // ids the launch shape visits, counted once over the whole ray grid
     for (long id = 0; id < d->nrays; ++id)
         if (id_is_traced(p, d, nindices, id)) ++ntraced;
+    struct Bundle {
+        int ray[kWave];
+        int alive, x0, x1, y0, y1;    // live rays and their bounding box in ray coordinates
+        bool used;
+    };
+    std::vector<Bundle> bundles;
+    bundles.reserve(order.size());
     for (auto &o : order) {
         const int bx = (o.second % px) * 8, by = (o.second / px) * 8;
-        int patch[kWave];
-        int alive = 0;
+        Bundle b{};
+        b.x0 = b.y0 = 1 << 30; b.x1 = b.y1 = -1;
         for (int l = 0; l < kWave; ++l) {
             const int rx = bx + (l & 7), ry = by + (l >> 3);
-            patch[l] = -1;
+            b.ray[l] = -1;
             if (rx >= d->nrays_x || ry >= d->nrays_y) continue;
             const long tile = (long)(ry / rpz) * zx + rx / rpz;           // inverse of :72-73
             const long id = tile * rpz2 + (ry % rpz) * rpz + rx % rpz;    // inverse of :70-71
             if (id >= d->nrays || !id_is_traced(p, d, nindices, id)) continue;
             const double ref = std::sqrt(xl[rx] * xl[rx] + yl[ry] * yl[ry]);
             if (!(ref <= kBeamMax)) continue;
-            patch[l] = (int)id;
-            ++alive;
+            b.ray[l] = (int)id;
+            ++b.alive;
+            b.x0 = std::min(b.x0, rx); b.x1 = std::max(b.x1, rx); b.y0 = std::min(b.y0, ry); b.y1 = std::max(b.y1, ry);
         }
-        if (!alive) continue;
-        slots.insert(slots.end(), patch, patch + kWave);
-        nlive += alive;
+        if (b.alive) bundles.push_back(b);
+    }
+    // cbet_params.rim_merge: patches on the rim of the beam hold fewer than 64 live rays, and those rays cross the whole
+    // box -- the longest bundles would run with idle lanes (256^3: 144 of 1620 bundles, lane utilisation 0.907).
+    // Neighbouring rim patches are packed into one bundle while their rays fit 64 lanes and a footprint of rim_merge rays
+    // per axis (1574 bundles, 0.940; 17.9 -> 17.55 ms per pass).  A ray keeps the lane of its patch position where that
+    // lane is free, so rays that share a zone still differ in the lane bits that pick the corner order.
+    const int merge_w = p->rim_merge;
+    for (size_t i = 0; i < bundles.size(); ++i) {
+        Bundle &b = bundles[i];
+        if (b.used) continue;
+        if (merge_w > 0 && b.alive < kWave) {
+            std::vector<std::pair<long, size_t>> cand;   // unused partial bundles, nearest first
+            for (size_t j = i + 1; j < bundles.size(); ++j) {
+                const Bundle &c = bundles[j];
+                if (c.used || c.alive >= kWave) continue;
+                const long dx = (c.x0 + c.x1) - (b.x0 + b.x1), dy = (c.y0 + c.y1) - (b.y0 + b.y1);
+                cand.emplace_back(dx * dx + dy * dy, j);
+            }
+            std::sort(cand.begin(), cand.end());
+            std::vector<int> extra;                       // rays whose own lane is taken
+            for (size_t k = 0; k < cand.size() && k < 12; ++k) {
+                Bundle &c = bundles[cand[k].second];
+                if (b.alive + c.alive > kWave) continue;
+                const int x0 = std::min(b.x0, c.x0), x1 = std::max(b.x1, c.x1), y0 = std::min(b.y0, c.y0), y1 = std::max(b.y1, c.y1);
+                if (x1 - x0 + 1 > merge_w || y1 - y0 + 1 > merge_w) continue;
+                for (int l = 0; l < kWave; ++l) {
+                    if (c.ray[l] < 0) continue;
+                    if (b.ray[l] < 0) b.ray[l] = c.ray[l];
+                    else extra.push_back(c.ray[l]);
+                }
+                b.alive += c.alive; b.x0 = x0; b.x1 = x1; b.y0 = y0; b.y1 = y1;
+                c.used = true;
+            }
+            for (int l = 0, e = 0; l < kWave && e < (int)extra.size(); ++l)
+                if (b.ray[l] < 0) b.ray[l] = extra[e++];
+        }
+        slots.insert(slots.end(), b.ray, b.ray + kWave);
+        nlive += b.alive;
     }
 }
 
@@ -243,6 +289,7 @@ int cbet_params_default(cbet_params *p, int n)
     p->shard_count = 1;
     p->kernel_variant = CBET_KERNEL_DEFAULT;
     p->patch_order = 1;
+    p->rim_merge = 16;
     return CBET_OK;
 }
 
@@ -482,7 +529,7 @@ static int check_geometry(const cbet_context *ctx, const cbet_params *p)
         p->ymin != q.ymin || p->ymax != q.ymax || p->zmin != q.zmin || p->zmax != q.zmax ||
         p->rays_per_zone != q.rays_per_zone || p->nbeams != q.nbeams || p->nprofile != q.nprofile ||
         p->max_threads != q.max_threads || p->threads_per_block != q.threads_per_block ||
-        p->courant_mult != q.courant_mult || p->patch_order != q.patch_order)
+        p->courant_mult != q.courant_mult || p->patch_order != q.patch_order || p->rim_merge != q.rim_merge)
         return fail(CBET_EINVAL, "launch parameters do not match the geometry the context was created for");
     return CBET_OK;
 }

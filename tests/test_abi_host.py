@@ -105,20 +105,44 @@ def test_live_list_is_the_reference_ray_set(api, oracle, inputs, n):
 
 
 def test_bundles_are_compact_patches(api, oracle, inputs):
-    """One bundle = an 8x8-ray patch: its launch points span at most 2 cells in-plane, and only
-    patches on the beam edge have holes."""
+    """One bundle = an 8x8-ray patch: its launch points span at most 2 cells in-plane, and only patches on the rim of
+    the beam have holes.  With cbet_params.rim_merge (default 16) neighbouring rim patches are packed into one bundle:
+    the same rays, fewer bundles, fewer idle lanes, a footprint of at most 16 rays = 4 cells."""
     bn = inputs[0]
-    p = api.default_params(256)
-    d = api.derive(p)
-    slots = api.live_ray_list(p)
-    fill = (slots.reshape(-1, 64) >= 0).sum(1)
-    assert (fill == 64).mean() > 0.9 and fill.sum() == d.nlive_rays == 98872
-    assert d.nlive_rays / len(slots) > 0.95           # idle lanes from holes: < 5 %
     cfg = oracle.default_config(256)
-    for k in (0, 640, 64 * 700, len(slots) - 64):
-        ids = slots[k:k + 64]
-        pts = np.array([oracle.launch_point(cfg, bn, 11, int(i))[1][:3] for i in ids[ids >= 0]])
-        assert np.ptp(pts, axis=0).max() <= 2.0 * d.dx * 1.0001
+
+    def spans(p, slots, picks):
+        d = api.derive(p)
+        out = []
+        for k in picks:
+            ids = slots[k:k + 64]
+            pts = np.array([oracle.launch_point(cfg, bn, 11, int(i))[1][:3] for i in ids[ids >= 0]])
+            out.append(np.ptp(pts, axis=0).max() / d.dx)
+        return out
+
+    p0 = api.default_params(256, rim_merge=0)
+    d = api.derive(p0)
+    s0 = api.live_ray_list(p0)
+    fill0 = (s0.reshape(-1, 64) >= 0).sum(1)
+    assert len(fill0) == 1620 and (fill0 == 64).mean() > 0.9 and fill0.sum() == d.nlive_rays == 98872
+    assert d.nlive_rays / len(s0) > 0.95           # idle lanes from holes: < 5 %
+    assert max(spans(p0, s0, (0, 640, 64 * 700, len(s0) - 64))) <= 2.0 * 1.0001
+    p = api.default_params(256)
+    assert p.rim_merge == 16
+    s = api.live_ray_list(p)
+    fill = (s.reshape(-1, 64) >= 0).sum(1)
+    assert sorted(s[s >= 0].tolist()) == sorted(s0[s0 >= 0].tolist())          # the same rays, each once
+    assert len(fill) < 1580 and d.nlive_rays / len(s) > 0.98 and (fill < 64).sum() < 100
+    partial = [64 * int(k) for k in np.nonzero(fill < 64)[0][:6]] + [64 * int(k) for k in np.argsort(-fill)[:2]]
+    merged = [64 * int(k) for k in range(len(fill)) if len(set((s[64 * k:64 * k + 64][s[64 * k:64 * k + 64] >= 0] // 16).tolist())) > 4][:8]
+    assert merged                                                                # bundles that hold rays of more than 4 zones
+    assert max(spans(p, s, partial + merged)) <= 4.0 * 1.0001
+    # the order of the full patches is untouched: the full bundles appear in the same sequence
+    full0 = [tuple(b) for b in s0.reshape(-1, 64) if (b >= 0).all()]
+    full = [tuple(b) for b in s.reshape(-1, 64) if tuple(b) in set(full0)]
+    assert full == full0
+    with pytest.raises(api.CbetError):
+        api.live_ray_list(api.default_params(64, rim_merge=5))
 
 
 def test_shard_plan_partitions_the_work(api):

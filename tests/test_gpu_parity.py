@@ -454,6 +454,36 @@ def test_patch_orders_trace_the_same_rays(api, inputs, oracle, torch_cuda):
         assert np.array_equal(l, lists[0])
 
 
+def test_rim_merge_traces_the_same_rays(api, inputs, oracle, torch_cuda):
+    """cbet_params.rim_merge packs neighbouring rim patches of the beam into one bundle (default: a footprint of 16
+    rays): off, the default and wider footprints list every live ray once, deposit the oracle's grid with the
+    oracle's step count -- in all three kernel formulations -- and the packed lists are shorter."""
+    bn, r, ne, te = inputs
+    beams = [3, 21, 40]
+    cfg = oracle.default_config(72, nbeams=3)
+    want, steps = oracle.trace(cfg, bn[beams], r, ne, te, nthreads=NCPU)
+    lists, lengths = [], []
+    for merge in (0, 16, 24, 64):
+        tr = make_tracer(api, inputs, 72, beams=beams, rim_merge=merge)
+        live = api.live_ray_list(tr.params)
+        lists.append(np.sort(live[live >= 0]))
+        lengths.append(len(live))
+        for variant in ((3, 1, 2) if merge in (0, 16) else (3,)):
+            e, c = run(tr, torch_cuda, kernel_variant=variant)
+            assert c.ray_steps == steps, (merge, variant)
+            assert parity_err(e, want) < PARITY_TOL, (merge, variant)
+        tr.close()
+    assert all(np.array_equal(l, lists[0]) for l in lists[1:])
+    assert lengths[0] > lengths[1] >= lengths[2] >= lengths[3]
+    tr = make_tracer(api, inputs, 40, beams=[0])
+    d = tr.derived
+    with pytest.raises(api.CbetError) as ei:     # the packing is part of the geometry a context is created for
+        api.launch_ray_XYZ(0, d.nindices, tr.d_te, tr.d_r, tr.d_ne, tr.new_grid(), tr.d_bbeam_norm, tr.d_beam_norm,
+                           tr.d_pow_r, tr.d_phase_r, d.xconst, d.yconst, d.zconst, tr.params.copy(rim_merge=0), ctx=tr.ctx)
+    assert ei.value.code == api.EINVAL
+    tr.close()
+
+
 def test_window_kernel_combines_and_is_parity_exact(api, oracle, inputs, torch_cuda):
     """The LDS windows only reorder fp64 sums: same grid and step count as the oracle on a beam subset whose
     bundles fan out in every direction, with most deposits combined in LDS before they reach HBM."""
