@@ -214,6 +214,7 @@ def main():
     ap.add_argument("--rays-per-zone", type=int, default=4, help="def.cuh:58 ships 4; BASELINE config 5 as stated (1.13e6 ray "
                     "ids per beam at 512^3) is 6")
     ap.add_argument("--patch-order", type=int, default=None, help="cbet_params.patch_order (default: the library's)")
+    ap.add_argument("--rim-merge", type=int, default=None, help="cbet_params.rim_merge (default: the library's 16; 0 = one 8x8 patch per bundle)")
     ap.add_argument("--variant", type=int, default=0, help="cbet_params.kernel_variant (0 = default)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank flow on a 1-GPU box together with CBET_BENCH_DEVICE)")
@@ -249,7 +250,8 @@ def main():
     r, ne, te = api.load_s83177()
     bn = api.omega60_beam_norm()
     p = api.default_params(n, kernel_variant=args.variant, rays_per_zone=args.rays_per_zone,
-                           **({} if args.patch_order is None else {"patch_order": args.patch_order}))
+                           **({} if args.patch_order is None else {"patch_order": args.patch_order}),
+                           **({} if args.rim_merge is None else {"rim_merge": args.rim_merge}))
     workload = "omega60_%dcube_s83177_absorption" % n + ("" if args.rays_per_zone == 4 else "_rpz%d" % args.rays_per_zone)
     tr = RayTracer(p, r, ne, te, beam_norm=bn)
     d = tr.derived

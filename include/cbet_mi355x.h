@@ -85,11 +85,12 @@ typedef struct cbet_params {
                                  /* (default): the arrays hold all nbeams grids.  This is how a rank of the    */
                                  /* slab-owned CBET loop keeps only ITS beams' fields and gain.                */
     int rim_merge;               /* patches on the rim of the beam cross-section hold fewer than 64 live rays:  */
-                                 /* neighbouring ones are packed into one bundle while the rays fit 64 lanes    */
-                                 /* and a footprint of rim_merge rays per axis (default 16 = 4 zones at 4 rays  */
-                                 /* per zone; 0 = every bundle is one 8x8 patch).  The same rays are traced;    */
-                                 /* at 256^3 lane utilisation goes from 0.907 to 0.940.  Part of the geometry   */
-                                 /* a context is created for.                                                   */
+                                 /* their rays are pooled, walked by angle around the beam axis and cut into    */
+                                 /* bundles of up to 64 rays with a footprint of at most rim_merge rays per     */
+                                 /* axis (default 16 = 4 zones at 4 rays per zone; 0 = every bundle is one 8x8  */
+                                 /* patch).  The same rays are traced; at 256^3 lane utilisation goes from      */
+                                 /* 0.907 to 0.957 (1620 -> 1552 bundles per beam).  Part of the geometry a     */
+                                 /* context is created for.                                                     */
 } cbet_params;
 
 /* Quantities the reference derives in def.cuh / main.cu:156-161, evaluated in the same order. */
@@ -136,7 +137,7 @@ int cbet_derive(const cbet_params *p, cbet_derived *d);
 /*
  * The beam-independent launch list, in the order the trace kernel consumes it.  The beam cross
  * section is cut into 8x8-ray patches (cbet_params.patch_order); 64 consecutive entries = one ray bundle = one
- * wavefront: one patch, or several rim patches packed together (cbet_params.rim_merge).  An entry is the thread-ray id (launch_ray_XZ.cu:125,156) of that ray,
+ * wavefront: one patch, or rays of the rim patches packed together (cbet_params.rim_merge; those bundles come first).  An entry is the thread-ray id (launch_ray_XZ.cu:125,156) of that ray,
  * or -1 for a hole: a ray the reference launch shape never visits or one that fails init()'s
  * beam-radius test (:94,114).  Work items g are (beam, patch) pairs, beam by beam, patch by patch;
  * shard s of K traces the items [s T / K, (s + 1) T / K) of the T in the list.
