@@ -309,7 +309,7 @@ def main():
             "config": {"workload": workload, "grid": n, "beams": 60, "rays_per_zone": args.rays_per_zone,
                        "edep_sum": edep_sum, "backend": args.backend if world > 1 else None,
                        "ray_steps_per_pass": steps_total / args.steps,
-                       "rays_per_pass": 60 * int(d.nlive_rays), "kernel_variant": args.variant,
+                       "rays_per_pass": 60 * int(d.nlive_rays), "kernel_variant": args.variant, "rim_merge": int(p.rim_merge),
                        "sharding": "contiguous 1/%d parts of the beam-major ray-bundle list, %s" % (shards, COMBINE_NOTE),
                        **({"shard_emulation": "rank %d of %d on one GPU, no process group (--shard-of): `value` is this "
                                               "share's rate, a profiling aid, not a bench line" % (shards // 2, shards)}
