@@ -108,7 +108,7 @@ EXPORTS = [
     "cbet_last_error", "cbet_version", "cbet_params_default", "cbet_derive",
     "cbet_live_ray_list", "cbet_omega60_beam_norm", "cbet_host_power_table", "cbet_host_beam_trig", "cbet_read_profile",
     "cbet_safeGPUAlloc", "cbet_moveToAndFromGPU", "cbet_gpuFree",
-    "cbet_context_create", "cbet_context_destroy", "cbet_context_counters", "cbet_context_tables",
+    "cbet_context_create", "cbet_context_destroy", "cbet_context_counters", "cbet_context_tables", "cbet_context_set_launch_list",
     "cbet_launch_ray_XYZ", "cbet_tabulate_plasma", "cbet_trace_nodes", "cbet_prepare_step_records", "cbet_ray_tracing",
     "cbet_write_text", "cbet_edep_average", "cbet_edep_average_device", "cbet_node_coordinates", "cbet_write_npy",
     "cbet_debug_bounds_violations",
@@ -153,6 +153,7 @@ def lib():
     L.cbet_context_create.argtypes = [C.POINTER(vp), C.POINTER(Params), C.c_int]
     L.cbet_context_destroy.argtypes = [vp]
     L.cbet_context_counters.argtypes = [vp, vp, C.POINTER(Counters), C.c_int]
+    L.cbet_context_set_launch_list.argtypes = [vp, ip, C.c_long]
     L.cbet_context_tables.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.cbet_launch_ray_XYZ.argtypes = [C.c_int, C.c_uint, vp, vp, vp, vp, vp, vp, vp, vp,
                                       C.c_double, C.c_double, C.c_double, C.POINTER(Params), vp, vp]
@@ -330,6 +331,11 @@ class Context:
         c = Counters()
         _check(lib().cbet_context_counters(self._h, _addr(stream), C.byref(c), 1 if reset else 0))
         return c
+
+    def set_launch_list(self, slots):
+        """Regroup the bundles: `slots` holds the context's live rays, each once, 64 entries per bundle, -1 = idle lane."""
+        arr = np.ascontiguousarray(slots, dtype=np.int32)
+        _check(lib().cbet_context_set_launch_list(self._h, arr.ctypes.data_as(C.POINTER(C.c_int)), arr.size))
 
     def tables(self):
         a, b = C.c_void_p(), C.c_void_p()

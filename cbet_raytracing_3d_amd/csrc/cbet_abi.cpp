@@ -429,6 +429,41 @@ int cbet_context_destroy(cbet_context *ctx)
     return CBET_OK;
 }
 
+// A caller that knows how long its rays live (a previous pass's per-ray step counts, a model) may regroup the bundles:
+// the same rays, every one exactly once, in any grouping of 64 and any order.  Synchronises the device (a launch may
+// still be reading the old list).
+int cbet_context_set_launch_list(cbet_context *ctx, const int *list, long n)
+{
+    if (!ctx || !list) return fail(CBET_EINVAL, "NULL context or list");
+    if (n <= 0 || n % kWave != 0) return fail(CBET_EINVAL, "a launch list is a whole number of 64-entry bundles (got %ld entries)", n);
+    DeviceGuard guard;
+    CBET_HIP(hipSetDevice(ctx->gpu));
+    CBET_HIP(hipDeviceSynchronize());
+    std::vector<int> cur((size_t)ctx->nlive), want, got;
+    if (ctx->nlive) CBET_HIP(hipMemcpy(cur.data(), ctx->live, cur.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (int v : cur) if (v >= 0) want.push_back(v);
+    for (long i = 0; i < n; ++i) {
+        if (list[i] >= 0) got.push_back(list[i]);
+        else if (list[i] != -1) return fail(CBET_EINVAL, "launch list entry %ld is %d (a ray id or -1)", i, list[i]);
+    }
+    for (long b = 0; b < n; b += kWave) {
+        bool any = false;
+        for (int l = 0; l < kWave; ++l) any = any || list[b + l] >= 0;
+        if (!any) return fail(CBET_EINVAL, "bundle %ld of the launch list is empty", b / kWave);
+    }
+    std::sort(want.begin(), want.end());
+    std::sort(got.begin(), got.end());
+    if (want != got) return fail(CBET_EINVAL, "the launch list must hold exactly the context's live rays, each once (%zu given, %zu expected)", got.size(), want.size());
+    int *fresh = nullptr;
+    CBET_HIP(hipMalloc((void **)&fresh, (size_t)n * sizeof(int)));
+    hipError_t e = hipMemcpy(fresh, list, (size_t)n * sizeof(int), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(fresh); return fail(CBET_EHIP, "hipMemcpy(launch list): %s", hipGetErrorString(e)); }
+    (void)hipFree(ctx->live);
+    ctx->live = fresh;
+    ctx->nlive = (int)n;
+    return CBET_OK;
+}
+
 int cbet_context_create(cbet_context **out, const cbet_params *p, int gpu)
 {
     if (!out) return fail(CBET_EINVAL, "ctx out-pointer is NULL");

@@ -182,6 +182,13 @@ int cbet_context_destroy(cbet_context *ctx);
 /* Synchronises `stream`, copies the counters to *out and, if reset != 0, zeroes them. */
 int cbet_context_counters(cbet_context *ctx, void *stream, cbet_counters *out, int reset);
 /*
+ * Replace the context's launch list (cbet_live_ray_list's layout: 64 entries per bundle, -1 = idle lane) by a
+ * regrouping of the SAME rays -- every live ray exactly once, no empty bundle; anything else is CBET_EINVAL.  For a
+ * caller that knows how long its rays live (e.g. from a previous pass) and wants bundles of rays that end together;
+ * the trace deposits the same sums in a different order.  Synchronises the device.
+ */
+int cbet_context_set_launch_list(cbet_context *ctx, const int *list, long n);
+/*
  * Device pointers of the context's own node tables (for tests / the 3-D plasma entry below).  They are writable:
  * the call marks the tables as modified, so the next launch that uses them (ne3d = kappa3d = NULL) rebuilds the
  * per-node step records it gathers from.  Call it again (or cbet_prepare_step_records) after EVERY later in-place

@@ -484,6 +484,43 @@ def test_rim_merge_traces_the_same_rays(api, inputs, oracle, torch_cuda):
     tr.close()
 
 
+def test_a_callers_launch_list_regroups_the_same_rays(api, inputs, oracle, torch_cuda):
+    """cbet_context_set_launch_list: any regrouping of the context's live rays into bundles of 64 traces the same
+    rays (here: bundles reversed, lanes rotated, and the rays dealt round-robin into twice as many half-empty bundles);
+    a list that drops, repeats or invents a ray, or has an empty bundle, is refused."""
+    bn, r, ne, te = inputs
+    tr = make_tracer(api, inputs, 48, beams=[5, 33])
+    want, steps = oracle.trace(oracle.default_config(48, nbeams=2), bn[[5, 33]], r, ne, te, nthreads=NCPU)
+    live = api.live_ray_list(tr.params).reshape(-1, 64)
+    e0, c0 = run(tr, torch_cuda)
+    assert c0.ray_steps == steps and parity_err(e0, want) < PARITY_TOL
+    ids = live[live >= 0]
+    dealt = -np.ones((2 * len(live), 64), dtype=np.int32)
+    for k, v in enumerate(ids):
+        dealt[k % len(dealt), k // len(dealt)] = v
+    dealt = dealt[(dealt >= 0).any(1)]
+    for lists in (np.roll(live[::-1], 5, axis=1), dealt):
+        tr.ctx.set_launch_list(lists.ravel())
+        e, c = run(tr, torch_cuda)
+        assert c.ray_steps == steps
+        assert parity_err(e, want) < PARITY_TOL
+    bad = live.copy().ravel()
+    first = int(np.nonzero(bad >= 0)[0][0])
+    for wrong in (bad[:-64], np.concatenate([bad, -np.ones(64, dtype=bad.dtype)]), bad[:-1]):
+        with pytest.raises(api.CbetError) as ei:
+            tr.ctx.set_launch_list(wrong)
+        assert ei.value.code == api.EINVAL
+    dup = bad.copy(); dup[first] = bad[np.nonzero(bad >= 0)[0][1]]
+    inv = bad.copy(); inv[first] = -7
+    for wrong in (dup, inv):
+        with pytest.raises(api.CbetError) as ei:
+            tr.ctx.set_launch_list(wrong)
+        assert ei.value.code == api.EINVAL
+    e, c = run(tr, torch_cuda)                      # the refused calls left the last good list in place
+    assert c.ray_steps == steps and parity_err(e, want) < PARITY_TOL
+    tr.close()
+
+
 def test_window_kernel_combines_and_is_parity_exact(api, oracle, inputs, torch_cuda):
     """The LDS windows only reorder fp64 sums: same grid and step count as the oracle on a beam subset whose
     bundles fan out in every direction, with most deposits combined in LDS before they reach HBM."""
