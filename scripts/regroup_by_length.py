@@ -3,7 +3,7 @@ the core: bundles there mix 200-step and 450-step rays.)  Ray lengths come from 
 spherical); inside every 2x2 block of whole 8x8 patches whose lanes are less than `thr` busy the 256 rays are sorted by
 length and cut into four bundles (a ray keeps its patch lane where free), the list is handed to the context
 (cbet_context_set_launch_list) and the 256^3 pass timed against the shipped list.
-usage: python scripts/regroup_by_length.py [thr=0.97]"""
+usage: python scripts/regroup_by_length.py [thr=0.97] [halves]"""
 import os, sys
 from multiprocessing import Pool
 import numpy as np, torch
@@ -49,6 +49,35 @@ if __name__ == "__main__":
     util = lambda rows: L[rows].sum() / (64.0 * L[rows].max(1).sum())
     new = live.copy()
     done = 0
+    halves = len(sys.argv) > 2 and sys.argv[2] == "halves"
+    if halves:
+        # gentler: two tangentially adjacent patches exchange halves -- the 32 longest rays of both in one bundle, the 32
+        # shortest in the other (roughly their outer and inner halves: a footprint of 8 x 16 rays, contiguous)
+        by_pos = {(int(rx[i].min()) // 8, int(ry[i].min()) // 8): int(i) for i in np.nonzero(whole_patch)[0]}
+        used = set()
+        for (px, py), i in sorted(by_pos.items()):
+            if i in used or util([i]) >= thr:
+                continue
+            cx, cy = 8 * px + 4 - d.nrays_x / 2, 8 * py + 4 - d.nrays_y / 2
+            cand = [(px, py + 1), (px, py - 1)] if abs(cx) > abs(cy) else [(px + 1, py), (px - 1, py)]
+            j = next((by_pos[c] for c in cand if c in by_pos and by_pos[c] not in used and util([by_pos[c]]) < thr), None)
+            if j is None:
+                continue
+            used |= {i, j}
+            rows = [i, j]
+            ids, lens, xs, ys = live[rows].ravel(), L[rows].ravel(), rx[rows].ravel(), ry[rows].ravel()
+            oi, oj = np.argsort(-lens[:64], kind="stable"), 64 + np.argsort(-lens[64:], kind="stable")
+            for row, sel in ((i, np.concatenate([oi[:32], oj[:32]])), (j, np.concatenate([oi[32:], oj[32:]]))):
+                bundle, extra = -np.ones(64, dtype=np.int64), []
+                for k in sel:
+                    lane = (xs[k] & 7) + 8 * (ys[k] & 7)
+                    if bundle[lane] < 0: bundle[lane] = ids[k]
+                    else: extra.append(ids[k])
+                free = np.nonzero(bundle < 0)[0]
+                bundle[free[:len(extra)]] = extra
+                new[row] = bundle
+            done += 2
+        blocks = {}
     for key, rows in blocks.items():
         if len(rows) < 2 or util(rows) >= thr:
             continue
