@@ -214,7 +214,7 @@ def main():
     ap.add_argument("--rays-per-zone", type=int, default=4, help="def.cuh:58 ships 4; BASELINE config 5 as stated (1.13e6 ray "
                     "ids per beam at 512^3) is 6")
     ap.add_argument("--patch-order", type=int, default=None, help="cbet_params.patch_order (default: the library's)")
-    ap.add_argument("--rim-merge", type=int, default=None, help="cbet_params.rim_merge (default: the library's 16; 0 = one 8x8 patch per bundle)")
+    ap.add_argument("--rim-merge", type=int, default=None, help="cbet_params.rim_merge in launch zones (default: the library's 4; 0 = one 8x8 patch per bundle)")
     ap.add_argument("--variant", type=int, default=0, help="cbet_params.kernel_variant (0 = default)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank flow on a 1-GPU box together with CBET_BENCH_DEVICE)")

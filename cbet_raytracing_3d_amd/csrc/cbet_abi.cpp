@@ -69,8 +69,8 @@ static int validate(const cbet_params *p)
     if (p->max_threads < 1 || p->threads_per_block < 1) return fail(CBET_EINVAL, "bad launch-shape rule");
     if (p->shard_count > 1 && (p->shard_index < 0 || p->shard_index >= p->shard_count))
         return fail(CBET_EINVAL, "shard_index outside [0, shard_count)");
-    if (p->rim_merge != 0 && (p->rim_merge < 8 || p->rim_merge > 64))
-        return fail(CBET_EINVAL, "rim_merge must be 0 (off) or a footprint of 8 .. 64 rays");
+    if (p->rim_merge != 0 && (p->rim_merge < 2 || p->rim_merge > 16))
+        return fail(CBET_EINVAL, "rim_merge must be 0 (off) or a footprint of 2 .. 16 launch zones");
     return CBET_OK;
 }
 
@@ -183,12 +183,14 @@ static void build_live_list(const cbet_params *p, const cbet_derived *d, int nin
     // cbet_params.rim_merge: patches on the rim of the beam hold fewer than 64 live rays, and those rays cross the whole
     // box -- the longest bundles would run with idle lanes (256^3: 144 of 1620 bundles, lane utilisation 0.907).  The rays
     // of all partial patches are pooled, walked by their angle around the beam axis and cut into bundles of up to 64 rays
-    // whose footprint stays within rim_merge rays per axis (16: 76 bundles instead of 144, lane utilisation 0.957).  A
+    // whose footprint stays within rim_merge launch zones per axis (4 = 16 rays: 76 bundles instead of 144, 0.957).  A
     // ray keeps the lane of its patch position where that lane is free, so rays that share a zone still differ in the
     // lane bits that pick the corner order.  The rim bundles -- the longest rays -- head the list.
-    const int merge_w = p->rim_merge;
+    const int merge_w = p->rim_merge > 0 ? std::max(8, p->rim_merge * rpz) : 0;   // in rays, never narrower than a patch
     std::vector<RimRay> pool;
     std::vector<int> full;                // the whole patches, in visit order
+    std::vector<int> partial;             // the rim patches as they are (kept if packing them gains nothing)
+    std::vector<int> packed;
     for (auto &o : order) {
         const int bx = (o.second % px) * 8, by = (o.second / px) * 8;
         int patch[kWave];
@@ -208,6 +210,7 @@ static void build_live_list(const cbet_params *p, const cbet_derived *d, int nin
         if (!alive) continue;
         nlive += alive;
         if (merge_w > 0 && alive < kWave) {
+            partial.insert(partial.end(), patch, patch + kWave);
             for (int l = 0; l < kWave; ++l)
                 if (patch[l] >= 0) {
                     const int rx = bx + (l & 7), ry = by + (l >> 3);
@@ -237,9 +240,11 @@ static void build_live_list(const cbet_params *p, const cbet_derived *d, int nin
         }
         for (int l = 0, q = 0; l < kWave && q < (int)extra.size(); ++l)
             if (bundle[l] < 0) bundle[l] = extra[q++];
-        slots.insert(slots.end(), bundle, bundle + kWave);
+        packed.insert(packed.end(), bundle, bundle + kWave);
         s0 = e;
     }
+    const std::vector<int> &rim = packed.size() < partial.size() ? packed : partial;
+    slots.insert(slots.end(), rim.begin(), rim.end());
     slots.insert(slots.end(), full.begin(), full.end());
 }
 
@@ -290,7 +295,7 @@ int cbet_params_default(cbet_params *p, int n)
     p->shard_count = 1;
     p->kernel_variant = CBET_KERNEL_DEFAULT;
     p->patch_order = 1;
-    p->rim_merge = 16;
+    p->rim_merge = 4;
     return CBET_OK;
 }
 

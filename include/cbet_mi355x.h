@@ -86,9 +86,9 @@ typedef struct cbet_params {
                                  /* slab-owned CBET loop keeps only ITS beams' fields and gain.                */
     int rim_merge;               /* patches on the rim of the beam cross-section hold fewer than 64 live rays:  */
                                  /* their rays are pooled, walked by angle around the beam axis and cut into    */
-                                 /* bundles of up to 64 rays with a footprint of at most rim_merge rays per     */
-                                 /* axis (default 16 = 4 zones at 4 rays per zone; 0 = every bundle is one 8x8  */
-                                 /* patch).  The same rays are traced; at 256^3 lane utilisation goes from      */
+                                 /* bundles of up to 64 rays with a footprint of at most rim_merge launch zones */
+                                 /* (= cells) per axis (default 4: 16 rays at 4 rays per zone; 0 = every bundle */
+                                 /* is one 8x8 patch).  The same rays are traced; at 256^3 lane utilisation goes from */
                                  /* 0.907 to 0.957 (1620 -> 1552 bundles per beam).  Part of the geometry a     */
                                  /* context is created for.                                                     */
 } cbet_params;

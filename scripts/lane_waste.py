@@ -51,6 +51,6 @@ if __name__ == "__main__":
         L0 = np.array(pool.map(lengths, range(len(live0)), chunksize=8))
     report("one 8x8 patch per bundle (rim_merge = 0)", live0, L0)
     steps = {int(i): int(s) for i, s in zip(live0.ravel(), L0.ravel()) if i >= 0}
-    for w in (16,):
+    for w in (4,):
         live = api.live_ray_list(api.default_params(n, rim_merge=w)).reshape(-1, 64)
         report("rim_merge = %d" % w, live, np.array([[steps[int(i)] if i >= 0 else 0 for i in b] for b in live]))

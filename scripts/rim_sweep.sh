@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: rim_sweep.sh w... : the 256^3 pass with cbet_params.rim_merge = w (0 = one 8x8 patch per bundle)
+# usage: rim_sweep.sh w... : the 256^3 pass with cbet_params.rim_merge = w launch zones (0 = one 8x8 patch per bundle)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 for m in "$@"; do
   timeout -k 10 120 python3 bench.py --steps 20 --warmup 5 --no-cbet --no-cpu-baseline --rim-merge $m 2>/dev/null | python3 -c "

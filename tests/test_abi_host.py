@@ -106,7 +106,7 @@ def test_live_list_is_the_reference_ray_set(api, oracle, inputs, n):
 
 def test_bundles_are_compact_patches(api, oracle, inputs):
     """One bundle = an 8x8-ray patch: its launch points span at most 2 cells in-plane, and only patches on the rim of
-    the beam have holes.  With cbet_params.rim_merge (default 16) the rays of the rim patches are packed into full bundles:
+    the beam have holes.  With cbet_params.rim_merge (default 4 launch zones = 16 rays) the rays of the rim patches are packed into full bundles:
     the same rays, fewer bundles, fewer idle lanes, a footprint of at most 16 rays = 4 cells."""
     bn = inputs[0]
     cfg = oracle.default_config(256)
@@ -128,7 +128,7 @@ def test_bundles_are_compact_patches(api, oracle, inputs):
     assert d.nlive_rays / len(s0) > 0.95           # idle lanes from holes: < 5 %
     assert max(spans(p0, s0, (0, 640, 64 * 700, len(s0) - 64))) <= 2.0 * 1.0001
     p = api.default_params(256)
-    assert p.rim_merge == 16
+    assert p.rim_merge == 4
     s = api.live_ray_list(p)
     fill = (s.reshape(-1, 64) >= 0).sum(1)
     assert sorted(s[s >= 0].tolist()) == sorted(s0[s0 >= 0].tolist())          # the same rays, each once
@@ -142,7 +142,7 @@ def test_bundles_are_compact_patches(api, oracle, inputs):
     full = [tuple(b) for b in s.reshape(-1, 64) if tuple(b) in set(full0)]
     assert full == full0
     with pytest.raises(api.CbetError):
-        api.live_ray_list(api.default_params(64, rim_merge=5))
+        api.live_ray_list(api.default_params(64, rim_merge=1))
 
 
 def test_shard_plan_partitions_the_work(api):
