@@ -52,15 +52,15 @@ struct Tile {
     static constexpr int XM = WX - 1, YM = WY - 1, ZM = WZ - 1;
     // Padded layout (doubles): ds_add_f64 costs the CU ~8 cycles when the lanes' addresses fall on different
     // bank pairs, +2 per lane sharing a bank, +3 per lane sharing an address (scripts/ubench/lds_atomic.hip),
-    // and a bundle's footprint is a few nodes wide per axis, so rows are padded by one entry and planes by four
-    // (the conflict-free pair (18, 149) for WZ = 16 measured no faster: its extra 576 bytes cost occupancy; the
-    // smaller (17, 136) and (16, 132) are 0.5 ms slower.  Round 3 scored every pair with the measured cost law on
-    // oracle ray paths, scripts/deposit_layouts.py --pads: nothing with XS <= 144 -- what 14 waves per CU leave --
-    // beats (17, 140); (19, 151) and (19, 153) save 14-15 % of the add cycles in the model and measure 18.4 ms
-    // against 18.3 at 13 waves per CU.)
+    // and a bundle's footprint is a few nodes wide per axis, so rows and planes are padded.  For the 8 x 8 x 16 box:
+    // rows of 18, planes of 148 -- with box B exactly the 11,520 B that still give 14 waves per CU (measured:
+    // 11,712 B do not, and the fourteenth wave is worth 0.9 ms).  Every (row, plane) pair was scored with the
+    // measured cost law on oracle ray paths (scripts/deposit_layouts.py --pads): (18, 148) 23.1 cycles per add
+    // against 25.8 for round 2's (17, 140), the best that fits 11,008 B; in interleaved runs 17.26 against 17.66 ms.
+    // The conflict-free (18, 149) and (19, 151 / 153) need one double / 24 - 40 doubles more and lose the wave.
     // PAD = false: the dense layout, for the rarely used second box.
-    static constexpr int YS = PAD ? WZ + 1 : WZ;
-    static constexpr int XS = PAD ? WY * YS + 4 : WY * WZ;
+    static constexpr int YS = PAD ? (WZ == 16 ? 18 : WZ + 1) : WZ;
+    static constexpr int XS = PAD ? (WZ == 16 ? 148 : WY * YS + 4) : WY * WZ;
     static constexpr int N = WX * XS;           // doubles per tile
     // largest offset of a lane's low corner from the origin at which its two nodes still lie inside
     static constexpr int SX = WX - 2, SY = WY - 2, SZ = WZ - 2;
