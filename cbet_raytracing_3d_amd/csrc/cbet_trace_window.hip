@@ -56,7 +56,7 @@ struct Tile {
     // rows of 18, planes of 148 -- with box B exactly the 11,520 B that still give 14 waves per CU (measured:
     // 11,712 B do not, and the fourteenth wave is worth 0.9 ms).  Every (row, plane) pair was scored with the
     // measured cost law on oracle ray paths (scripts/deposit_layouts.py --pads): (18, 148) 23.1 cycles per add
-    // against 25.8 for round 2's (17, 140), the best that fits 11,008 B; in interleaved runs 17.26 against 17.66 ms.
+    // against 25.8 for round 2's (17, 140), the best that fits 11,008 B; in interleaved runs 16.99 against 17.57 ms.
     // The conflict-free (18, 149) and (19, 151 / 153) need one double / 24 - 40 doubles more and lose the wave.
     // PAD = false: the dense layout, for the rarely used second box.
     static constexpr int YS = PAD ? (WZ == 16 ? 18 : WZ + 1) : WZ;
