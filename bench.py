@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: ray-steps/sec of the OMEGA 60-beam sweep (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step = one full pass of the hot path over the workload: zero the deposition grid, tabulate the
@@ -205,6 +205,28 @@ def roofline(prof, steps_per_launch, kernel_s, tot, steps_total):
     return out
 
 
+def spawn_ranks(ngpus):
+    """Start `ngpus` ranks of this script under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1 at a
+    free port) and return the launcher's exit code.  Runs before anything in this process has touched the GPU."""
+    import socket
+    import subprocess
+    if "CBET_BENCH_DEVICE" not in os.environ:     # (the rehearsal override puts every rank on one device)
+        import torch                              # device_count() does not create a HIP context
+        have = torch.cuda.device_count()
+        if ngpus > have:
+            print("bench.py: --gpus %d but this node has %d HIP device(s)" % (ngpus, have), file=sys.stderr)
+            return 2
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -225,6 +247,14 @@ def main():
     ap.add_argument("--no-cbet", action="store_true", help="skip the (unpinned) CBET-iteration leg reported beside the headline")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` with no launcher: this process becomes the launcher (the counterpart of the one
+        # OpenMP thread per GPU of main.cu:166-176).  It never touches the GPU -- the ranks are fresh children of
+        # torch.distributed.run, no exec from a process that holds a HIP context -- and relays their output and exit code.
+        sys.exit(spawn_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
     from cbet_raytracing_3d_amd import api
@@ -233,11 +263,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
     device_index = int(os.environ.get("CBET_BENCH_DEVICE", local_rank))  # rehearsal override only
+    if device_index >= torch.cuda.device_count():
+        raise SystemExit("rank %d wants device %d but this node has %d" % (rank, device_index, torch.cuda.device_count()))
     torch.cuda.set_device(device_index)
     if world > 1:
         if args.backend == "nccl":
@@ -245,6 +277,8 @@ def main():
                                     device_id=torch.device("cuda", device_index))
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:   # "n_gpus" below is what the process group really has
+            raise SystemExit("process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
 
     n = args.n
     r, ne, te = api.load_s83177()

@@ -47,3 +47,19 @@ def test_two_rank_line_carries_a_roofline():
     assert rl["frac"] is not None and 0.05 < rl["frac"] < 1.0 and "pmc_k2" in rl["traffic_source"]
     assert rl["traffic"] is not None and rl["hbm_measured_frac"] > 0
     assert pl["traces_overlap"] and pl["kernel_ms_alone"] > 0 and rl["kernel_ms"] == pytest.approx(pl["kernel_ms_alone"])
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher (how the driver's scaling run invokes it; main.cu:166-176 starts its
+    own per-GPU threads too): the script must start two ranks itself and rank 0 must report the process group's size."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["CBET_BENCH_DEVICE"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--grid", "64",
+           "--steps", "2", "--warmup", "1", "--no-cbet", "--no-cpu-baseline"]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert run.returncode == 0, run.stdout[-1500:] + run.stderr[-1500:]
+    lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["ray_steps_per_pass"] == 30712072
+    assert out["config"]["edep_sum"] == pytest.approx(6.1070952143e17, rel=1e-9)
