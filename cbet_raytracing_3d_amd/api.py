@@ -114,7 +114,7 @@ EXPORTS = [
     "cbet_debug_bounds_violations",
     "cbet_gain_params_default", "cbet_gain_constants", "cbet_trace_cbet", "cbet_gain_field",
     "cbet_cbet_workspace_bytes", "cbet_cbet_solve", "cbet_gain_field_slab", "cbet_gain_field_packed",
-    "cbet_cbet_slab_workspace_bytes", "cbet_pack_segments", "cbet_unpack_segments",
+    "cbet_cbet_slab_workspace_bytes", "cbet_cbet_slab_workspace_bytes_parts", "cbet_pack_segments", "cbet_unpack_segments",
 ]
 
 _lib = None
@@ -182,6 +182,8 @@ def lib():
     L.cbet_unpack_segments.argtypes = [vp, C.c_long, C.c_int, C.c_int, vp, C.c_long, vp, vp]
     L.cbet_cbet_slab_workspace_bytes.argtypes = [C.POINTER(Params), C.c_int, C.c_int]
     L.cbet_cbet_slab_workspace_bytes.restype = C.c_size_t
+    L.cbet_cbet_slab_workspace_bytes_parts.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.c_size_t]
+    L.cbet_cbet_slab_workspace_bytes_parts.restype = C.c_size_t
     L.cbet_cbet_workspace_bytes.argtypes = [C.POINTER(Params)]
     L.cbet_cbet_workspace_bytes.restype = C.c_size_t
     L.cbet_cbet_solve.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(Params), C.POINTER(GainParams), vp, vp, vp,
@@ -431,6 +433,10 @@ def unpack_segments(dst, beam_stride, hy, hz, segments, nseg, buf, stream=None):
 
 def cbet_slab_workspace_bytes(params, world_size, rank):
     return int(lib().cbet_cbet_slab_workspace_bytes(C.byref(params), world_size, rank))
+
+
+def cbet_slab_workspace_bytes_parts(params, own_beams, own_planes, staging_doubles=0):
+    return int(lib().cbet_cbet_slab_workspace_bytes_parts(C.byref(params), own_beams, own_planes, staging_doubles))
 
 
 def gain_field_slab(fields, ne3d, gain, scratch, change, hx_lo, hx_hi, params, gain_params, ctx, stream=None):

@@ -900,20 +900,24 @@ int cbet_gain_field_packed(double *fields, const double *ne3d, double *gain, dou
     return gain_field_impl(fields, ne3d, gain, scratch, change, hx_lo, hx_hi, true, p, g, ctx, stream);
 }
 
+size_t cbet_cbet_slab_workspace_bytes_parts(const cbet_params *p, int own_beams, int own_planes, size_t staging_doubles)
+{
+    if (!p || validate(p) != CBET_OK || own_beams < 0 || own_beams > p->nbeams || own_planes < 0 || own_planes > p->nx + 2) return 0;
+    const size_t plane = (size_t)(p->ny + 2) * (p->nz + 2), hsize = (size_t)(p->nx + 2) * plane, nb = (size_t)p->nbeams;
+    // own beams over the whole grid: 4 field components + gain; all beams over the own slab: 4 components + gain
+    // (the pair-once gain kernel keeps its sums in LDS: no scratch array since round 3; the dense exchange sends from and
+    // receives into these arrays: no staging since round 4)
+    return (5 * (size_t)own_beams * hsize + 5 * nb * (size_t)own_planes * plane + staging_doubles + 2 + CBET_MAX_CBET_BEAMS) * sizeof(double);
+}
+
 size_t cbet_cbet_slab_workspace_bytes(const cbet_params *p, int world_size, int rank)
 {
     if (!p || validate(p) != CBET_OK || world_size < 1 || rank < 0 || rank >= world_size) return 0;
-    const size_t plane = (size_t)(p->ny + 2) * (p->nz + 2), hsize = (size_t)(p->nx + 2) * plane, nb = (size_t)p->nbeams;
     // contiguous near-equal parts, as tracer._parts
+    const size_t nb = (size_t)p->nbeams;
     const size_t own_beams = ((size_t)(rank + 1) * nb) / world_size - ((size_t)rank * nb) / world_size;
     const size_t own_planes = ((size_t)(rank + 1) * (p->nx + 2)) / world_size - ((size_t)rank * (p->nx + 2)) / world_size;
-    // the exchange's send and receive staging buffers (tracer._Exchanger: one peer and one component at a time): the
-    // most beams a rank owns x the most planes a rank owns x one plane, each; nothing on one rank
-    const size_t max_beams = (nb + world_size - 1) / world_size, max_planes = ((size_t)p->nx + 2 + world_size - 1) / world_size;
-    const size_t staging = world_size > 1 ? 2 * max_beams * max_planes * plane : 0;
-    // own beams over the whole grid: 4 field components + gain; all beams over the own slab: 4 components + gain
-    // (the pair-once gain kernel keeps its sums in LDS: no scratch array since round 3)
-    return (5 * own_beams * hsize + 5 * nb * own_planes * plane + staging + 2 + CBET_MAX_CBET_BEAMS) * sizeof(double);
+    return cbet_cbet_slab_workspace_bytes_parts(p, (int)own_beams, (int)own_planes, 0);
 }
 
 static int gain_field_impl(double *fields, const double *ne3d, double *gain, double *scratch, double *change,

@@ -156,7 +156,7 @@ class RayTracer:
                                          sparse=sparse)
             rep["workspace_bytes"] = engine.slab_bytes()
             plan = engine.exchanger.plan
-            rep["exchange"] = {"chunks": engine.exchanger.chunks, "bytes_sent": engine.exchanger.bytes_sent,
+            rep["exchange"] = {"chunks": engine.exchanger.chunks, "messages": engine.exchanger.messages, "bytes_sent": engine.exchanger.bytes_sent,
                                "staging_bytes": engine.exchanger.staging_bytes(),
                                "sparse": plan is not None,
                                "runs_per_exchange": plan.runs_out if plan is not None else None,
@@ -391,21 +391,66 @@ class _DeviceCbetEngine:
         return self.beam_gain
 
     # ---- slab-owned loop: own beams [b0, b1) over the whole grid, all beams over the own planes [x0, x1)
-    def begin_slabs(self, b0, b1, x0, x1):
+    def begin_beams(self, b0, b1):
+        """This rank's beams over the whole grid (their fields are complete here without any reduction) and the two
+        trace streams the beam groups of a field pass alternate on."""
         tr, dev = self.tr, self.tr.device
-        nb, gs = tr.params.nbeams, tr.grid_shape
-        self.b0, self.b1, self.x0, self.x1 = b0, b1, x0, x1
+        self.b0, self.b1 = b0, b1
         f64 = dict(dtype=torch.float64, device=dev)
-        self.own_fields = torch.zeros((4, b1 - b0) + gs, **f64)
-        self.gain_own = torch.zeros((b1 - b0,) + gs, **f64)
+        self.own_fields = torch.zeros((4, b1 - b0) + tr.grid_shape, **f64)
+        self.gain_own = torch.zeros((b1 - b0,) + tr.grid_shape, **f64)
+        self.gain = self.gain_own            # what a caller gets back: this rank's beams over the whole grid
+        self.s_trace = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        self._launches = 0
+        tr.tabulate()
+        self.ev_ready = torch.cuda.Event()
+        self.ev_ready.record(torch.cuda.current_stream(dev))
+
+    def begin_slab(self, x0, x1):
+        """All beams over this rank's planes [x0, x1) (what its gain update reads and writes)."""
+        tr = self.tr
+        nb, gs = tr.params.nbeams, tr.grid_shape
+        self.x0, self.x1 = x0, x1
+        f64 = dict(dtype=torch.float64, device=tr.device)
         self.slab_fields = torch.zeros((4, nb, x1 - x0) + gs[1:], **f64)
         self.gain_slab = torch.zeros((nb, x1 - x0) + gs[1:], **f64)
-        self.gain = self.gain_own            # what a caller gets back: this rank's beams over the whole grid
-        tr.tabulate()
+
+    def begin_slabs(self, b0, b1, x0, x1):
+        self.begin_beams(b0, b1)
+        self.begin_slab(x0, x1)
+
+    def trace_group(self, i0, i1, use_gain, full=True, wait=()):
+        """The field pass of this rank's beams [b0 + i0, b0 + i1) -- one GROUP of a pass -- on the next of two alternating
+        trace streams, after the events in `wait` (the gain of these beams having arrived).  Consecutive groups overlap
+        (the drain of one launch beside the head of the next), and a finished group can be sent while the next one
+        traces.  Returns the event recorded behind the launch."""
+        tr = self.tr
+        st = self.s_trace[self._launches % 2]
+        self._launches += 1
+        st.wait_event(self.ev_ready)
+        for ev in wait:
+            if ev is not None:
+                st.wait_event(ev)
+        with torch.cuda.stream(st):
+            out = self.own_fields if full else self.own_fields[0]
+            (out[:, i0:i1] if full else out[i0:i1]).zero_()
+            tr.launch_cbet(out, self.gp, fields=True if full else "energy", gain=self.gain_own if use_gain else None,
+                           beam_lo=self.b0 + i0, beam_hi=self.b0 + i1, grid_beam0=self.b0, grid_beams=self.b1 - self.b0)
+            done = torch.cuda.Event()
+            done.record(st)
+        return done
+
+    def presence_counts(self):
+        """int32 [X][Y][Z]: how many of this rank's beams deposited energy at each node in the pass just traced (the
+        footprint the gain update's work follows)."""
+        cnt = torch.zeros(self.tr.grid_shape, dtype=torch.int32, device=self.tr.device)
+        for b in range(self.b1 - self.b0):
+            cnt += (self.own_fields[0, b] != 0).to(torch.int32)
+        return cnt
 
     def slab_bytes(self):
-        """Device bytes this rank's slab loop holds: the arrays of begin_slabs, the exchange's two staging buffers and
-        (sparse exchanges) the segment lists."""
+        """Device bytes this rank's slab loop holds: the arrays of begin_beams / begin_slab and, for sparse exchanges, the
+        staging buffers and segment lists (the dense exchange sends from and receives into the arrays themselves)."""
         arrays = 8 * sum(t.numel() for t in (self.own_fields, self.gain_own, self.slab_fields, self.gain_slab))
         xch = getattr(self, "exchanger", None)
         if xch is None:
@@ -435,11 +480,9 @@ class _DeviceCbetEngine:
         return mask
 
     def field_passes_beams(self, use_gain, full=True):
-        out = self.own_fields if full else self.own_fields[0]
-        out.zero_()
+        """The whole field pass of this rank's beams as one group; the current stream waits for it."""
         if self.b1 > self.b0:
-            self.tr.launch_cbet(out, self.gp, fields=True if full else "energy", gain=self.gain_own if use_gain else None,
-                                beam_lo=self.b0, beam_hi=self.b1, grid_beam0=self.b0, grid_beams=self.b1 - self.b0)
+            torch.cuda.current_stream(self.tr.device).wait_event(self.trace_group(0, self.b1 - self.b0, use_gain, full))
         return self.own_fields
 
     def update_gain_slab(self, frozen=False):
@@ -523,94 +566,186 @@ def _parts(total, world_size):
     return [((r * total) // world_size, ((r + 1) * total) // world_size) for r in range(world_size)]
 
 
-def exchange_staging_elems(nbeams, nx_halo, plane, world_size, force=False):
-    """Doubles in ONE staging buffer of the slab loop's exchanges (there are two: send and receive): the largest
-    chunk any exchange moves at once = the most beams a rank owns x the most planes a rank owns x one plane, for
-    one field component (cbet_cbet_slab_workspace_bytes counts 2 x this).  0 on one rank (nothing is exchanged)."""
-    if world_size <= 1 and not force:
-        return 0
-    return (-(-nbeams // world_size)) * (-(-nx_halo // world_size)) * plane
+def balanced_slabs(weights, world_size):
+    """Contiguous plane ranges [(lo, hi)] per rank whose summed `weights` (one per plane of the haloed grid) are as equal as
+    whole planes allow; every rank gets at least one plane while there are enough.  The same deterministic rule on every
+    rank (the weights come out of an all-reduce of integers)."""
+    w = np.asarray(weights, dtype=np.float64)
+    X = len(w)
+    if world_size >= X or not np.isfinite(w).all() or w.sum() <= 0:
+        return _parts(X, world_size)
+    cum = np.concatenate([[0.0], np.cumsum(w)])
+    cuts = [0]
+    for r in range(1, world_size):
+        target = cum[-1] * r / world_size
+        x = int(np.searchsorted(cum, target))
+        if x > 0 and abs(cum[x - 1] - target) <= abs(cum[min(x, X)] - target):
+            x -= 1
+        cuts.append(min(max(x, cuts[-1] + 1), X - (world_size - r)))
+    cuts.append(X)
+    return [(cuts[r], cuts[r + 1]) for r in range(world_size)]
 
 
-class _Exchanger:
-    """The all-to-all exchanges of the slab-owned CBET loop over point-to-point xGMI links (RCCL send/recv; gloo in the
-    CPU tests), stream-ordered and chunked:
+def gain_update_weights(counts):
+    """Per-plane cost of the gain update from the number of beams present at each node (`counts`, integer [X][Y][Z], summed
+    over ranks): the pair-once kernel's time splits into a part per cell (presence masks: 2.3 ms of a 256^3 / 60-beam
+    call), a part per present beam (normalise, stage, relax: 5.1 ms) and a part per beam PAIR (4.0 ms) -- timing builds
+    that skip phases, profiles/r3/experiments/gain_kernel.log.  Returns a float64 numpy array [X]."""
+    n = counts.to(torch.float64)
+    pairs = n * (n - 1.0) * 0.5
+    s0, s1, s2 = float(n.numel()), float(n.sum()), float(pairs.sum())
+    w = torch.full((n.shape[0],), 2.3 * n[0].numel() / s0, dtype=torch.float64, device=n.device)
+    if s1 > 0:
+        w += 5.1 * n.sum((1, 2)) / s1
+    if s2 > 0:
+        w += 4.0 * pairs.sum((1, 2)) / s2
+    return w.cpu().numpy()
 
-    * no host synchronisation with RCCL: the producer's stream records an event, everything below runs on a
-      communication stream that waits for it, and the consumer's stream waits for the event recorded at the end;
-    * one peer pair at a time, in W - 1 rounds: in round k rank r sends to r + k and receives from r - k (every link
-      of the point-to-point fabric carries one message per round, no rank is the target of two senders), and a
-      multi-component array moves one component at a time: the pack copy, the grouped send/recv and the unpack copy
-      of a chunk reuse ONE send and ONE receive staging buffer (sized by exchange_staging_elems, allocated once and
-      counted in cbet_cbet_slab_workspace_bytes) instead of a contiguous copy per peer all at once;
-    * with a backend that has no device path (gloo) device tensors are staged through the host, chunk by chunk.
 
-    rank r sends src[send_index(s)] to every other rank s and stores what s sends it in dst[recv_index(s)]; its own
-    part is copied.  Index tuples select strided views, the first index being the component axis when
-    `components` is true.  Empty parts (a rank without beams or planes) are skipped on both sides."""
+class _SlabExchanger:
+    """The two all-to-all exchanges of the slab-owned CBET loop over point-to-point xGMI links (RCCL send/recv; gloo in
+    the CPU tests), one message per (beam, peer, component) and NO staging: the part of a beam over an x-slab is
+    contiguous both in the sender's whole-grid array and in the receiver's slab array, so messages go from and into the
+    arrays themselves.
 
-    def __init__(self, device, staging_elems, group=None, force_collectives=False):
+    * All W - 1 peers at once: the sends of my i-th beam to every slab owner and the receives of every peer's i-th beam
+      are ONE grouped send/recv (batch_isend_irecv = ncclGroupStart ... End), so all seven links of a rank carry a
+      message at the same time.  Chunks are beams (and components), never peers.
+    * Stream-ordered: everything runs on a communication stream that waits for the producer's event (the trace of the
+      beam's group; the gain update) and hands an event to the consumer (the gain update; the next trace of the group) --
+      no host synchronisation.  A group's fields travel while the next group traces; a group's gain comes back while
+      the previous groups already trace the next pass.
+    * gloo has no device path: device tensors are staged through the host message by message (tests only).
+    Ranks without beams or planes simply post nothing; every rank walks the beam indices in the same order, so the
+    sends and receives of a pair match in order."""
+
+    def __init__(self, device, group, rank, world_size, beams, force_collectives=False):
         import torch.distributed as dist
-        self.group, self.device = group, torch.device(device)
+        self.group, self.device, self.rank, self.world, self.beams = group, torch.device(device), rank, world_size, beams
         self.cuda = self.device.type == "cuda"
-        self.nccl = self.cuda and dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"
-        self.force = force_collectives      # run the send/recv machinery on one rank too (a self-exchange: RCCL smoke test)
+        self.dist_on = dist.is_available() and dist.is_initialized()
+        self.nccl = self.cuda and self.dist_on and dist.get_backend(group) == "nccl"
+        self.force = force_collectives      # one rank: the same send/recv machinery as a self-exchange (RCCL smoke test)
         self.stream = torch.cuda.Stream(device=self.device) if self.nccl else None
-        stage_dev = self.device if (self.nccl or not self.cuda) else torch.device("cpu")
-        self.send_buf = torch.empty(staging_elems, dtype=torch.float64, device=stage_dev)
-        self.recv_buf = torch.empty(staging_elems, dtype=torch.float64, device=stage_dev)
-        self.chunks = 0                     # chunks moved so far (tests, logs)
-        self.bytes_sent = 0
+        self.solo = world_size == 1
+        self.peers = [rank] if (self.solo and self.force) else [r for r in range(world_size) if r != rank]
+        self.slabs = None
+        self.plan = None
+        self.send_buf = self.recv_buf = None    # sparse exchanges only
+        self.chunks = self.messages = self.bytes_sent = 0
+
+    def set_slabs(self, slabs):
+        self.slabs = slabs
 
     def staging_bytes(self):
-        return 8 * (self.send_buf.numel() + self.recv_buf.numel()) if self.send_buf.device == self.device else 0
+        if self.send_buf is None or self.send_buf.device != self.device:
+            return 0
+        return 8 * (self.send_buf.numel() + self.recv_buf.numel())
 
-    def _chunks(self, view, components):
-        if view.numel() == 0:
-            return []
-        return [view[c] for c in range(view.shape[0])] if components else [view]
-
-    def run(self, src, send_index, dst, recv_index, rank, world_size, components=False):
+    def _global(self, r):
         import torch.distributed as dist
-        dst[recv_index(rank)] = src[send_index(rank)]
-        if world_size == 1 and not self.force:
+        return r if self.group is None else dist.get_global_rank(self.group, r)
+
+    def _enter(self, after):
+        """Order what follows behind the events in `after`: on the communication stream (RCCL) or the current one."""
+        target = self.stream if self.nccl else (torch.cuda.current_stream(self.device) if self.cuda else None)
+        if target is not None:
+            for ev in after:
+                if ev is not None:
+                    target.wait_event(ev)
+        return torch.cuda.stream(self.stream) if self.nccl else _NullContext()
+
+    def _leave(self):
+        """An event behind everything issued so far (None without a device)."""
+        if not self.cuda:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self.stream if self.nccl else torch.cuda.current_stream(self.device))
+        return ev
+
+    def fence(self):
+        return self._leave()
+
+    def _batch(self, sends, recvs):
+        """One grouped send/recv: `sends` / `recvs` are (tensor view, peer) lists of contiguous views."""
+        import torch.distributed as dist
+        if not sends and not recvs:
             return
-        producer = torch.cuda.current_stream(self.device) if self.nccl else None
-        if self.nccl:
-            ev = torch.cuda.Event()
-            ev.record(producer)
-            self.stream.wait_event(ev)
-        ctx = torch.cuda.stream(self.stream) if self.nccl else _NullContext()
-        with ctx:
-            rounds = range(1, world_size) if world_size > 1 else [0]      # [0]: the forced self-exchange of one rank
-            for k in rounds:
-                to, frm = (rank + k) % world_size, (rank - k) % world_size
-                outs = self._chunks(src[send_index(to)], components)
-                wants = self._chunks(dst[recv_index(frm)], components)
-                for c in range(max(len(outs), len(wants))):
-                    ops = []
-                    if c < len(outs):
-                        n = outs[c].numel()
-                        sb = self.send_buf[:n].view(outs[c].shape)
-                        sb.copy_(outs[c])                                # pack (device: on the communication stream)
-                        peer = to if self.group is None else dist.get_global_rank(self.group, to)
-                        ops.append(dist.P2POp(dist.isend, sb, peer, self.group))
-                        self.bytes_sent += 8 * n
-                    if c < len(wants):
-                        m = wants[c].numel()
-                        rb = self.recv_buf[:m].view(wants[c].shape)
-                        peer = frm if self.group is None else dist.get_global_rank(self.group, frm)
-                        ops.append(dist.P2POp(dist.irecv, rb, peer, self.group))
-                    if ops:
-                        for req in dist.batch_isend_irecv(ops):
-                            req.wait()     # RCCL: the communication stream waits (no host block); gloo: the host waits
-                        self.chunks += 1
-                    if c < len(wants):
-                        wants[c].copy_(rb)                               # unpack
-        if self.nccl:
-            done = torch.cuda.Event()
-            done.record(self.stream)
-            producer.wait_event(done)
+        ops, late = [], []
+        for t, peer in sends:
+            if self.cuda and not self.nccl:
+                t = t.cpu()                         # gloo: through the host (synchronises the current stream)
+            ops.append(dist.P2POp(dist.isend, t, self._global(peer), self.group))
+            self.bytes_sent += 8 * t.numel()
+        for t, peer in recvs:
+            if self.cuda and not self.nccl:
+                h = torch.empty(t.shape, dtype=t.dtype, device="cpu")
+                late.append((t, h))
+                t = h
+            ops.append(dist.P2POp(dist.irecv, t, self._global(peer), self.group))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()     # RCCL: the communication stream waits (no host block); gloo: the host waits
+        for t, h in late:
+            t.copy_(h)
+        self.chunks += 1
+        self.messages += len(ops)
+
+    def fields_out(self, own, slab, i0, i1, comps, after=()):
+        """Exchange 1 for the beams with index [i0, i1) of every rank: my beams' fields over slab s -> rank s, rank q's
+        beams over my slab <- rank q, component by component of `comps`.  own: [4][my beams][X][Y][Z], slab:
+        [4][all beams][my planes][Y][Z]."""
+        rank, beams, slabs = self.rank, self.beams, self.slabs
+        b0, b1 = beams[rank]
+        x0, x1 = slabs[rank]
+        with self._enter(after):
+            for i in range(i0, i1):
+                sends, recvs = [], []
+                mine = i < b1 - b0
+                for s_ in self.peers:
+                    xs0, xs1 = slabs[s_]
+                    if mine and xs1 > xs0:
+                        sends += [(own[c, i, xs0:xs1], s_) for c in comps]
+                    q0, q1 = beams[s_]
+                    if i < q1 - q0 and x1 > x0:
+                        recvs += [(slab[c, q0 + i], s_) for c in comps]
+                if mine and x1 > x0 and not (self.solo and self.force):
+                    for c in comps:
+                        slab[c, b0 + i].copy_(own[c, i, x0:x1])       # the own part never travels
+                self._batch(sends, recvs)
+        return self._leave()
+
+    def gain_back(self, gain_slab, gain_own, i0, i1, after=()):
+        """Exchange 2 for the beams with index [i0, i1): the new gain of rank q's beams over my slab -> rank q, my beams'
+        gain over slab s <- rank s.  gain_slab: [all beams][my planes][Y][Z], gain_own: [my beams][X][Y][Z].  Returns the
+        event behind it: the next pass's trace of these beams waits for it."""
+        rank, beams, slabs = self.rank, self.beams, self.slabs
+        b0, b1 = beams[rank]
+        x0, x1 = slabs[rank]
+        with self._enter(after):
+            for i in range(i0, i1):
+                sends, recvs = [], []
+                mine = i < b1 - b0
+                for q in self.peers:
+                    q0, q1 = beams[q]
+                    if i < q1 - q0 and x1 > x0:
+                        sends.append((gain_slab[q0 + i], q))
+                    xs0, xs1 = slabs[q]
+                    if mine and xs1 > xs0:
+                        recvs.append((gain_own[i, xs0:xs1], q))
+                if mine and x1 > x0 and not (self.solo and self.force):
+                    gain_own[i, x0:x1].copy_(gain_slab[b0 + i])
+                self._batch(sends, recvs)
+        return self._leave()
+
+    # ---- the sparse form: only the 64-byte z-runs inside the beams' footprints move (SegmentPlan) --------------------
+    def use_plan(self, plan):
+        """Sparse exchanges: staging for the runs of ALL peers of one component at once, out and in."""
+        self.plan = plan
+        stage_dev = self.device if (self.nccl or not self.cuda) else torch.device("cpu")
+        peers = self.peers
+        n_out = 8 * max(sum(plan.own_side[s].shape[0] for s in peers), sum(plan.slab_side[q].shape[0] for q in peers))
+        self.send_buf = torch.empty(n_out, dtype=torch.float64, device=stage_dev)
+        self.recv_buf = torch.empty(n_out, dtype=torch.float64, device=stage_dev)
 
     def _pack(self, arr, stride, hy, hz, seg, out):
         n = seg.shape[0]
@@ -628,60 +763,51 @@ class _Exchanger:
             idx, valid = _pack_rows_cpu(arr, stride, hz, seg)
             arr.view(-1)[idx[valid]] = buf[: 8 * n].view(n, 8)[valid]
 
-    def run_sparse(self, src, send_index, dst, recv_index, plan, to_slabs, rank, world_size, ncomp=0):
-        """The same exchange, moving only the 64-byte z-runs of `plan` (SegmentPlan): to_slabs = exchange 1 (my beams'
-        fields to the slab owners: pack from my whole-grid array, unpack into my slab array), else exchange 2 (the gain of
-        the peers' beams over my slab back to them).  ncomp > 0: the arrays carry that many leading components, one message
-        each.  One peer pair per round, every message through the two staging buffers, stream-ordered as in run()."""
+    def run_sparse(self, src, send_index, dst, recv_index, to_slabs, ncomp=0, after=()):
+        """One exchange moving only the z-runs of the plan: to_slabs = exchange 1 (pack from my whole-grid array, unpack
+        into my slab array), else exchange 2.  ncomp > 0: the arrays carry that many leading components.  Per component:
+        the runs of ALL peers are packed into consecutive stretches of the send staging buffer, travel in one grouped
+        send/recv, and are unpacked from the receive staging buffer.  Stream-ordered like the dense form."""
         import torch.distributed as dist
-        dst[recv_index(rank)] = src[send_index(rank)]       # the own part: a dense local copy
-        if world_size == 1 and not self.force:
-            return
+        plan, rank = self.plan, self.rank
         hy, hz = plan.Y, plan.Z
         out_lists, in_lists = (plan.own_side, plan.slab_side) if to_slabs else (plan.slab_side, plan.own_side)
         out_stride, in_stride = (plan.own_stride, plan.slab_stride) if to_slabs else (plan.slab_stride, plan.own_stride)
         dev_stage = self.send_buf.device == src.device
-        producer = torch.cuda.current_stream(self.device) if self.nccl else None
-        if self.nccl:
-            ev = torch.cuda.Event()
-            ev.record(producer)
-            self.stream.wait_event(ev)
-        with (torch.cuda.stream(self.stream) if self.nccl else _NullContext()):
-            rounds = range(1, world_size) if world_size > 1 else [0]
-            for k in rounds:
-                to, frm = (rank + k) % world_size, (rank - k) % world_size
-                seg_out, seg_in = out_lists[to], in_lists[frm]
-                n_out, n_in = seg_out.shape[0], seg_in.shape[0]
-                for c in range(max(1, ncomp)):
-                    s_arr = src[c] if ncomp else src
-                    d_arr = dst[c] if ncomp else dst
-                    ops = []
+        with self._enter(after):
+            if not (self.solo and self.force):
+                dst[recv_index(rank)] = src[send_index(rank)]       # the own part: a dense local copy
+            for c in range(max(1, ncomp)):
+                s_arr = src[c] if ncomp else src
+                d_arr = dst[c] if ncomp else dst
+                ops, off_out, off_in, unpack = [], 0, 0, []
+                for peer in self.peers:
+                    seg_out, seg_in = out_lists[peer], in_lists[peer]
+                    n_out, n_in = seg_out.shape[0], seg_in.shape[0]
                     if n_out:
+                        sb = self.send_buf[off_out: off_out + 8 * n_out]
                         if dev_stage:
-                            self._pack(s_arr, out_stride, hy, hz, seg_out, self.send_buf)
-                            sb = self.send_buf[: 8 * n_out]
+                            self._pack(s_arr, out_stride, hy, hz, seg_out, sb)
                         else:                   # gloo with device arrays: pack on the device, stage through the host
                             tmp = torch.empty(8 * n_out, dtype=torch.float64, device=src.device)
                             self._pack(s_arr, out_stride, hy, hz, seg_out, tmp)
-                            sb = self.send_buf[: 8 * n_out]
                             sb.copy_(tmp)
-                        peer = to if self.group is None else dist.get_global_rank(self.group, to)
-                        ops.append(dist.P2POp(dist.isend, sb, peer, self.group))
+                        ops.append(dist.P2POp(dist.isend, sb, self._global(peer), self.group))
                         self.bytes_sent += 64 * n_out
+                        off_out += 8 * n_out
                     if n_in:
-                        rb = self.recv_buf[: 8 * n_in]
-                        peer = frm if self.group is None else dist.get_global_rank(self.group, frm)
-                        ops.append(dist.P2POp(dist.irecv, rb, peer, self.group))
-                    if ops:
-                        for req in dist.batch_isend_irecv(ops):
-                            req.wait()
-                        self.chunks += 1
-                    if n_in:
-                        self._unpack(d_arr, in_stride, hy, hz, seg_in, rb if dev_stage else rb.to(dst.device))
-        if self.nccl:
-            done = torch.cuda.Event()
-            done.record(self.stream)
-            producer.wait_event(done)
+                        rb = self.recv_buf[off_in: off_in + 8 * n_in]
+                        ops.append(dist.P2POp(dist.irecv, rb, self._global(peer), self.group))
+                        unpack.append((seg_in, rb))
+                        off_in += 8 * n_in
+                if ops:
+                    for req in dist.batch_isend_irecv(ops):
+                        req.wait()
+                    self.chunks += 1
+                    self.messages += len(ops)
+                for seg_in, rb in unpack:
+                    self._unpack(d_arr, in_stride, hy, hz, seg_in, rb if dev_stage else rb.to(dst.device))
+        return self._leave()
 
 
 def _segment_rows(support, x0, x1):
@@ -783,83 +909,133 @@ class _NullContext:
         return False
 
 
-def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_size=1, group=None, sparse=False):
-    """The CBET fixed-point iteration with storage and exchange sized for 8 ranks on point-to-point xGMI (SURVEY
+def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_size=1, group=None, sparse=False,
+                           trace_groups=4, balance=True):
+    """The CBET fixed-point iteration with storage, exchange and schedule sized for 8 ranks on point-to-point xGMI (SURVEY
     8(f) f1; parity unpinned; same passes and same result as cbet_fixed_point).
 
     Rank r traces WHOLE beams [b_r0, b_r1) -- their four fields are complete on r without any reduction -- and
     owns the x-slab [x_r0, x_r1) of the deposit grid for the gain update.  It STORES only
         its own beams over the whole grid : own_fields [4][nb_r][X][Y][Z], gain_own [nb_r][X][Y][Z]
         all beams over its own slab       : slab_fields [4][nb][x_r][Y][Z], gain_slab [nb][x_r][Y][Z]
-    i.e. (5 nb_r + 6 nb / W) grids instead of 6 nb: 92 GB per rank at 512^3 / 60 beams / 8 ranks against 391 GB
-    (cbet_cbet_slab_workspace_bytes).  Per pass: (1) every rank sends each slab owner its beams' fields over that
-    slab (all-to-all, (W-1)/W of own_fields); (2) each rank updates the gain of ALL beams on its slab; (3) it sends
-    every rank the gain of that rank's beams over its slab (all-to-all, gain_slab); (4) two scalars are
-    all-reduced for the convergence measure and rank 0's copy decides.  At 256^3 / 60 beams / 8 ranks that is
-    3.6 GB + 0.9 GB sent per rank in a direction-building pass (the first) and 0.9 GB + 0.9 GB in every later one
-    (energy field only), against 58 / 14 GB of ring traffic per rank for the all-reduce loop.
-    `engine`: begin_slabs(b0, b1, x0, x1); field_passes_beams(use_gain, full) -> own_fields; attributes slab_fields,
-    gain_slab, gain_own; update_gain_slab(frozen) -> tensor {sum |dK|, sum |K|} over the slab; deposit_beams() ->
-    beam_gain.  The deposition grid is left un-reduced (allreduce_grid / reduce_scatter_grid)."""
+    (cbet_cbet_slab_workspace_bytes_parts).  The slabs are cut by gain-update WORK, not by plane count (balance): after
+    the first (gain-free) field pass every rank counts its beams per node, the counts are all-reduced once and the
+    planes are dealt so that the modelled cost of the update (gain_update_weights) is equal -- the beams cross at the
+    centre, and with equal plane counts the central ranks' update takes twice the outer ranks'.
+
+    One pass, pipelined over beam GROUPS (trace_groups of them; engine.trace_group runs them on alternating streams):
+        trace group g  ->  exchange 1 of group g's beams (while group g + 1 traces): my beams' fields over slab s to
+        rank s, all peers of a beam in one grouped send/recv  ->  [all groups in]  gain update of ALL beams on my slab
+        ->  exchange 2, group by group in the order the next pass traces them: the gain of rank q's beams over my
+        slab back to q  ->  the next pass's trace of group g starts as soon as ITS gain is in.
+    The two scalars of the convergence measure are all-reduced and rank 0's copy decides, while exchange 2 is already
+    in flight.  At 256^3 / 60 beams / 8 ranks a rank sends 3.6 GB + 0.9 GB in the direction-building first pass and
+    0.9 GB + 0.9 GB in every later one (energy field only).  sparse=True: the un-pipelined exchange of only the z-runs
+    inside the beams' footprints (SegmentPlan; exact; does not pay for this physics, see profiles/r3/cbet_rank_share.log).
+    `engine`: begin_beams(b0, b1); trace_group(i0, i1, use_gain, full, wait) -> event or None; presence_counts() ->
+    integer [X][Y][Z]; begin_slab(x0, x1); attributes own_fields, gain_own, slab_fields, gain_slab;
+    update_gain_slab(frozen) -> tensor {sum |dK|, sum |K|} over the slab; deposit_beams() -> beam_gain.  The
+    deposition grid is left un-reduced (allreduce_grid / reduce_scatter_grid)."""
     import torch.distributed as dist
-    beams, slabs = _parts(nbeams, world_size), _parts(nx_halo, world_size)
-    (b0, b1), (x0, x1) = beams[rank], slabs[rank]
-    engine.begin_slabs(b0, b1, x0, x1)
-    plane = int(engine.slab_fields.shape[-1] * engine.slab_fields.shape[-2])
+    beams = _parts(nbeams, world_size)
+    b0, b1 = beams[rank]
+    nbr = b1 - b0
+    imax = max(q1 - q0 for q0, q1 in beams)
+    groups = [g for g in _parts(imax, max(1, min(trace_groups, imax))) if g[1] > g[0]]     # beam-INDEX ranges, the same on every rank
     force = getattr(engine, "force_collectives", False)   # one rank, but every collective really runs (RCCL smoke test)
-    # sparse = True: the exchanges move only the 64-byte z-runs a beam's rays can ever touch (SegmentPlan) instead of
-    # dense sub-arrays.  Exact, but it does not pay for this physics: traced to the exit of the grid whatever their energy
-    # -- the only footprint that is guaranteed to contain every pass's -- the refracted rays of an OMEGA beam visit 73 %
-    # of the nodes of the 256^3 grid (83 % of its z-runs), and the pack / unpack kernels of 0.8 GB take longer (0.84 ms per
-    # exchange) than the dense exchange's strided copies (0.57 ms): profiles/r3/cbet_rank_share.log.  Kept as an option
-    # for plasmas / beam sets whose footprint is small.
-    support = engine.support_mask() if (sparse and hasattr(engine, "support_mask") and (world_size > 1 or force)) else None
-    plan = SegmentPlan(support, beams, slabs, rank, world_size, group, engine.slab_fields.device) if support is not None else None
-    del support
-    staging = plan.staging_elems() if plan is not None else exchange_staging_elems(nbeams, nx_halo, plane, world_size, force)
-    xch = _Exchanger(engine.slab_fields.device, staging, group, force_collectives=force)
-    xch.plan = plan
+    engine.begin_beams(b0, b1)
+    xch = _SlabExchanger(engine.own_fields.device, group, rank, world_size, beams, force_collectives=force)
     engine.exchanger = xch
+    on_device = engine.own_fields.is_cuda
+    cur = (lambda: torch.cuda.current_stream(engine.own_fields.device)) if on_device else None
+
+    def wait_here(events):
+        if on_device:
+            for ev in events:
+                if ev is not None:
+                    cur().wait_event(ev)
+
+    def mark():
+        if not on_device:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(cur())
+        return ev
+
+    def all_reduce_host_staged(t):
+        if world_size > 1 or force:
+            if t.is_cuda and dist.get_backend(group) != "nccl":
+                host = t.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+                return host
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return t
+
+    # sparse = True: the exchanges move only the 64-byte z-runs a beam's rays can ever touch instead of dense sub-arrays.
+    # Exact, but it does not pay for this physics: 73 % of the nodes are inside a beam's footprint.  (The footprint pass
+    # uses the field arrays as scratch and resets the counters: before the first field pass.)
+    support = engine.support_mask() if (sparse and hasattr(engine, "support_mask") and (world_size > 1 or force)) else None
+    slabs, plan = None, None
+    gain_ev = [None] * len(groups)
     rep = {"passes": 0, "converged": False, "change": float("inf")}
     for it in range(gain_params.max_passes):
         full = it < gain_params.direction_passes
-        comps = slice(None) if full else slice(0, 1)    # after the direction-building passes only the energy field moves
-        own = engine.field_passes_beams(it > 0, full)
-        # my beams' fields over slab s -> rank s; rank q's beams over my slab <- rank q
-        if plan is not None:
-            xch.run_sparse(own, lambda s: (comps, slice(None), slice(*slabs[s])),
-                           engine.slab_fields, lambda q: (comps, slice(*beams[q])), plan, True, rank, world_size,
-                           ncomp=4 if full else 1)
-        else:
-            xch.run(own, lambda s: (comps, slice(None), slice(*slabs[s])),
-                    engine.slab_fields, lambda q: (comps, slice(*beams[q])), rank, world_size, components=True)
-        ch = engine.update_gain_slab(not full)
-        if world_size > 1 or force:
-            if ch.is_cuda and dist.get_backend(group) != "nccl":
-                host = ch.cpu()
-                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
-                ch = host
+        comps = range(4) if full else range(1)    # after the direction-building passes only the energy field moves
+        traced = []
+        for g, (i0, i1) in enumerate(groups):
+            j0, j1 = min(i0, nbr), min(i1, nbr)
+            traced.append(engine.trace_group(j0, j1, it > 0, full, wait=(gain_ev[g],)) if j1 > j0 else None)
+            if slabs is not None and plan is None:
+                xch.fields_out(engine.own_fields, engine.slab_fields, i0, i1, comps, after=(traced[g],))
+        if slabs is None:
+            # first pass: the beams' footprints are known now -- cut the slabs, allocate them, then send everything
+            wait_here(traced)
+            if balance and world_size > 1:
+                counts = all_reduce_host_staged(engine.presence_counts())
+                slabs = balanced_slabs(gain_update_weights(counts), world_size)
+                del counts
             else:
-                dist.all_reduce(ch, op=dist.ReduceOp.SUM, group=group)
-        # the gain of rank q's beams over my slab -> rank q; my beams' gain over slab s <- rank s
+                slabs = _parts(nx_halo, world_size)
+            engine.begin_slab(*slabs[rank])
+            xch.set_slabs(slabs)
+            if support is not None:
+                plan = SegmentPlan(support, beams, slabs, rank, world_size, group, engine.slab_fields.device)
+                support = None
+                xch.use_plan(plan)
+            if plan is None:
+                for g, (i0, i1) in enumerate(groups):
+                    xch.fields_out(engine.own_fields, engine.slab_fields, i0, i1, comps, after=(traced[g],))
         if plan is not None:
-            xch.run_sparse(engine.gain_slab, lambda q: (slice(*beams[q]),),
-                           engine.gain_own, lambda s: (slice(None), slice(*slabs[s])), plan, False, rank, world_size)
+            xch.run_sparse(engine.own_fields, lambda s_: (slice(0, len(comps)), slice(None), slice(*slabs[s_])),
+                           engine.slab_fields, lambda q: (slice(0, len(comps)), slice(*beams[q])), True,
+                           ncomp=len(comps), after=traced)
+        wait_here([xch.fence()])                     # every beam's fields over my slab are in
+        ch = all_reduce_host_staged(engine.update_gain_slab(not full))
+        updated = mark()
+        # the gain of rank q's beams over my slab -> rank q; my beams' gain over slab s <- rank s: group by group, in the
+        # order the next pass traces them (and before the host learns whether there is a next pass: the deposition
+        # pass needs the new gain as well)
+        if plan is not None:
+            ev = xch.run_sparse(engine.gain_slab, lambda q: (slice(*beams[q]),),
+                                engine.gain_own, lambda s_: (slice(None), slice(*slabs[s_])), False, after=(updated,))
+            gain_ev = [ev] * len(groups)
         else:
-            xch.run(engine.gain_slab, lambda q: (slice(*beams[q]),),
-                    engine.gain_own, lambda s: (slice(None), slice(*slabs[s])), rank, world_size)
+            gain_ev = [xch.gain_back(engine.gain_slab, engine.gain_own, i0, i1, after=(updated,)) for i0, i1 in groups]
         ch = _agree(ch, group, world_size)
         rep["passes"] = it + 1
         rep["change"] = float(ch[0] / ch[1]) if float(ch[1]) > 0 else 0.0
         if rep["change"] < gain_params.tolerance:
             rep["converged"] = True
             break
+    wait_here(gain_ev)
     beam_gain = engine.deposit_beams()
     if world_size > 1 or force:
         allreduce_grid(beam_gain, group, force)
     bg = beam_gain.cpu().numpy().copy()
     rep["beam_gain"] = bg
     rep["imbalance"] = float(abs(bg.sum()) / np.abs(bg).sum()) if np.abs(bg).sum() > 0 else 0.0
+    rep["slabs"] = slabs
+    rep["groups"] = groups
     return rep
 
 

@@ -403,13 +403,18 @@ int cbet_unpack_segments(double *dst, long beam_stride, int hy, int hz, const in
                          void *stream);
 /*
  * Device bytes one rank of the slab-owned CBET loop (tracer.cbet_fixed_point_slabs) needs beside the node tables:
- * its own beams' four field components and gain over the whole grid, all beams' fields and gain over
- * its x-slab, and (world_size > 1) the two staging buffers of the chunked all-to-all exchanges -- one peer and one
- * field component at a time: ceil(nbeams / W) x ceil((nx+2) / W) x (ny+2)(nz+2) doubles each.  0 on bad arguments.
- * (512^3, 60 beams, 8 ranks: ~95 GB per rank, 2.2 GB of it staging; every rank holding everything,
- * cbet_cbet_workspace_bytes, would be 391 GB.)
+ * its own beams' four field components and gain over the whole grid and all beams' fields and gain over its x-slab.
+ * The dense exchanges need NO staging: a beam's part over a slab is contiguous in both layouts, so every message is
+ * sent from and received into the arrays themselves (one message per beam, peer and component; all peers of a beam
+ * in one grouped send/recv).  `_parts`: the rank holds own_beams beams and own_planes planes -- the slabs are cut by
+ * gain-update WORK (the central planes, where the beams cross, are the expensive ones), so the outer ranks hold more
+ * planes than (nx+2) / W -- plus staging_doubles of exchange staging (0; the optional sparse exchange packs its runs).
+ * cbet_cbet_slab_workspace_bytes(p, W, rank): the same with the equal cut of beams and planes (a lower bound for the outer
+ * ranks of a balanced cut).  0 on bad arguments.  (512^3, 60 beams, 8 ranks, equal cut: ~86 GB per rank; every rank
+ * holding everything, cbet_cbet_workspace_bytes, would be 391 GB.)
  */
 size_t cbet_cbet_slab_workspace_bytes(const cbet_params *p, int world_size, int rank);
+size_t cbet_cbet_slab_workspace_bytes_parts(const cbet_params *p, int own_beams, int own_planes, size_t staging_doubles);
 /* Bytes of device workspace cbet_cbet_solve needs: 5 nbeams (n+2)^3 doubles (four field components + gain) + a few scalars. */
 size_t cbet_cbet_workspace_bytes(const cbet_params *p);
 /*

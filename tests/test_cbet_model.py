@@ -136,7 +136,8 @@ def test_gain_params_and_constants_host_side(api, oracle, case):
 
 def test_slab_workspace_fits_config5(api):
     """BASELINE config 5 (512^3, 60 beams, 8 ranks): the slab-owned loop's per-rank storage must fit 288 GB of HBM
-    with the node tables and step records beside it; every rank holding everything would not (326 GB)."""
+    with the node tables and step records beside it; every rank holding everything would not (326 GB).  The dense
+    exchange sends from and receives into the arrays themselves: no staging."""
     p = api.default_params(512)
     hsize, plane = 514 ** 3, 514 ** 2
     tables = 8 * 512 ** 3 * (2 + 4) * 2             # ne3d + kappa3d + 32-byte step records, two buffer sets
@@ -145,15 +146,40 @@ def test_slab_workspace_fits_config5(api):
         b = api.cbet_slab_workspace_bytes(p, 8, rank)
         nb_r = (rank + 1) * 60 // 8 - rank * 60 // 8
         planes = (rank + 1) * 514 // 8 - rank * 514 // 8
-        staging = 2 * 8 * 65 * plane                 # send + receive: ceil(60/8) beams x ceil(514/8) planes, one component
-        assert b == 8 * (5 * nb_r * hsize + 5 * 60 * planes * plane + staging + 2 + api.MAX_CBET_BEAMS)
+        assert b == 8 * (5 * nb_r * hsize + 5 * 60 * planes * plane + 2 + api.MAX_CBET_BEAMS)
+        assert b == api.cbet_slab_workspace_bytes_parts(p, nb_r, planes, 0)
         worst = max(worst, b)
-    from cbet_raytracing_3d_amd.tracer import exchange_staging_elems
-    assert exchange_staging_elems(60, 514, plane, 8) == 8 * 65 * plane and exchange_staging_elems(60, 514, plane, 1) == 0
-    assert worst + tables < 288e9 and worst < 90e9    # staging included: 2.2 GB of the 88 GB
+    assert worst + tables < 288e9 and worst < 88e9
+    # slabs cut by gain-update work give the outer ranks more planes than 514 / 8: twice as many still fits
+    assert api.cbet_slab_workspace_bytes_parts(p, 8, 130, 0) + tables < 288e9
+    assert api.cbet_slab_workspace_bytes_parts(p, 8, 10, 1000) == api.cbet_slab_workspace_bytes_parts(p, 8, 10, 0) + 8000
+    assert api.cbet_slab_workspace_bytes_parts(p, 61, 10, 0) == 0 and api.cbet_slab_workspace_bytes_parts(p, 8, 515, 0) == 0
     assert api.cbet_workspace_bytes(p) > 288e9       # the all-reduce loop's whole-grid arrays do not fit
     assert api.cbet_slab_workspace_bytes(p, 8, 8) == 0 and api.cbet_slab_workspace_bytes(p, 0, 0) == 0
     assert api.cbet_slab_workspace_bytes(api.default_params(256), 1, 0) == api.cbet_workspace_bytes(api.default_params(256)) + 8 * 5 * 60 * 258 ** 3
+
+
+def test_balanced_slabs_rule():
+    """Slabs cut by work: contiguous, covering, at least one plane per rank, near-equal summed weight."""
+    from cbet_raytracing_3d_amd.tracer import _parts, balanced_slabs, gain_update_weights
+    rng = np.random.default_rng(3)
+    x = np.arange(258)
+    w = 1.0 + 40.0 * np.exp(-((x - 129) / 40.0) ** 2) + rng.uniform(0, 0.1, 258)      # the beams cross at the centre
+    for world in (1, 2, 3, 8):
+        cut = balanced_slabs(w, world)
+        assert cut[0][0] == 0 and cut[-1][1] == 258 and all(cut[r][1] == cut[r + 1][0] for r in range(world - 1))
+        assert all(hi > lo for lo, hi in cut)
+        sums = [w[lo:hi].sum() for lo, hi in cut]
+        assert max(sums) - min(sums) <= 2 * w.max()
+    c8 = balanced_slabs(w, 8)
+    assert c8[0][1] - c8[0][0] > 2 * (c8[3][1] - c8[3][0])          # outer slabs are much wider than central ones
+    assert balanced_slabs(np.zeros(10), 4) == _parts(10, 4) and balanced_slabs(np.ones(3), 5) == _parts(3, 5)
+    # the cost model: cells, present beams, beam pairs
+    cnt = torch.zeros((4, 3, 3), dtype=torch.int32)
+    cnt[1] = 2
+    cnt[2] = 4
+    gw = gain_update_weights(cnt)
+    assert gw[0] == gw[3] and gw[2] > gw[1] > gw[0] > 0 and abs(gw.sum() - (2.3 + 5.1 + 4.0)) < 1e-9
 
 
 class _OracleEngine:
@@ -197,13 +223,22 @@ class _OracleEngine:
 
     # the slab-owned loop (cbet_fixed_point_slabs): whole beams per rank, the gain update per x-slab, and only
     # (own beams x whole grid) + (all beams x own slab) stored -- torch tensors, filled in place by the exchange
-    def begin_slabs(self, b0, b1, x0, x1):
+    def begin_beams(self, b0, b1):
         gs = self.O.grid_shape(self.cfg)
-        self.b0, self.b1, self.x0, self.x1 = b0, b1, x0, x1
+        self.b0, self.b1 = b0, b1
+        self.own_fields = torch.zeros((4, b1 - b0) + gs, dtype=torch.float64)
         self.gain_own = torch.zeros((b1 - b0,) + gs, dtype=torch.float64)
+        self.groups_traced = 0
+
+    def begin_slab(self, x0, x1):
+        gs = self.O.grid_shape(self.cfg)
+        self.x0, self.x1 = x0, x1
         self.slab_fields = torch.zeros((4, self.nb, x1 - x0) + gs[1:], dtype=torch.float64)
         self.gain_slab = torch.zeros((self.nb, x1 - x0) + gs[1:], dtype=torch.float64)
-        self.stored = 4 * (b1 - b0) * int(np.prod(gs)) + self.gain_own.numel() + self.slab_fields.numel() + self.gain_slab.numel()
+        self.stored = self.own_fields.numel() + self.gain_own.numel() + self.slab_fields.numel() + self.gain_slab.numel()
+
+    def presence_counts(self):
+        return (self.own_fields[0] != 0).sum(0).to(torch.int32)
 
     def support_mask(self):
         # the rays of the own beams traced in bookkeeping mode (absorption = 0: no ray stops before it leaves the grid)
@@ -215,9 +250,10 @@ class _OracleEngine:
             out[b - self.b0] = e != 0
         return torch.from_numpy(out)
 
-    def _beam_items(self):
+    def _beam_items(self, lo=None, hi=None):
+        lo, hi = (self.b0 if lo is None else lo), (self.b1 if hi is None else hi)
         beams, ids = self.api.shard_items(self.p, self.nb, 0, 1)
-        keep = (np.asarray(beams) >= self.b0) & (np.asarray(beams) < self.b1)
+        keep = (np.asarray(beams) >= lo) & (np.asarray(beams) < hi)
         return np.asarray(beams)[keep], np.asarray(ids)[keep]
 
     def _full_gain(self):      # the oracle takes a gain array over all beams; only this rank's beams are traced
@@ -225,16 +261,14 @@ class _OracleEngine:
         g[self.b0:self.b1] = self.gain_own.numpy()
         return g
 
-    def field_passes_beams(self, use_gain, full=True):
-        qs = (1, 2, 3, 4) if full else (1,)
-        F = [self.O.trace_cbet(self.cfg, self.g, self.bn, self.ne3d, self.kap, gain=self._full_gain() if use_gain else None,
-                               quantity=q, per_beam=True, nthreads=2, items=self._beam_items())[0][self.b0:self.b1]
-             for q in qs]
-        if full:
-            self.own_fields = torch.from_numpy(np.stack(F))
-        else:
-            self.own_fields[0] = torch.from_numpy(np.ascontiguousarray(F[0]))
-        return self.own_fields
+    def trace_group(self, i0, i1, use_gain, full=True, wait=()):
+        # one group of this rank's beams: [b0 + i0, b0 + i1) (the device engine alternates two streams; nothing to wait for here)
+        self.groups_traced += 1
+        for c, q in enumerate((1, 2, 3, 4) if full else (1,)):
+            F = self.O.trace_cbet(self.cfg, self.g, self.bn, self.ne3d, self.kap, gain=self._full_gain() if use_gain else None,
+                                  quantity=q, per_beam=True, nthreads=2, items=self._beam_items(self.b0 + i0, self.b0 + i1))[0]
+            self.own_fields[c, i0:i1] = torch.from_numpy(np.ascontiguousarray(F[self.b0 + i0:self.b0 + i1]))
+        return None
 
     def update_gain_slab(self, frozen=False):
         # the oracle updates whole grids: embed the slab (zero fields elsewhere), keep the slab of the result
@@ -273,9 +307,20 @@ def _solve(rank, world, group=None, slabs=False, sparse=False):
         # what the rank stored: (5 nb_r + 5 nb / W) grids = 10 nb / W: the whole problem's 5 nb at two ranks, less beyond
         full = (N + 2) ** 3
         assert eng.stored == (5 * (eng.b1 - eng.b0) * (N + 2) + 5 * len(BEAMS) * (eng.x1 - eng.x0)) * (N + 2) ** 2
-        assert world == 1 or eng.stored <= 5 * len(BEAMS) * full * 2 // world + 5 * (N + 2) ** 3   # ragged split: one beam's grids of slack
+        assert eng.stored == 8 ** -1 * (api.cbet_slab_workspace_bytes_parts(eng.p, eng.b1 - eng.b0, eng.x1 - eng.x0, 0) - 8 * (2 + api.MAX_CBET_BEAMS))
+        cut = rep["slabs"]
+        assert cut[rank] == (eng.x0, eng.x1) and cut[0][0] == 0 and cut[-1][1] == N + 2 and all(hi > lo for lo, hi in cut)
+        assert all(cut[r][1] == cut[r + 1][0] for r in range(world - 1))
+        assert eng.groups_traced >= rep["passes"] * min(len(rep["groups"]), 1)
         if world > 1 and not sparse:
-            assert eng.exchanger.plan is None and eng.exchanger.chunks > 0
+            xch = eng.exchanger
+            assert xch.plan is None and xch.chunks > 0 and xch.staging_bytes() == 0
+            # dense: one message per (beam, peer, component): what this rank sent is its beams over the other ranks' slabs
+            # (4 components in the direction passes, 1 afterwards) + the other ranks' beams' gain over its own slab
+            npass, ndir, plane = rep["passes"], gp.direction_passes, (N + 2) ** 2
+            others = (N + 2) - (eng.x1 - eng.x0)
+            want = 8 * plane * ((eng.b1 - eng.b0) * others * (4 * ndir + (npass - ndir)) + (len(BEAMS) - (eng.b1 - eng.b0)) * (eng.x1 - eng.x0) * npass)
+            assert xch.bytes_sent == want
         if world > 1 and sparse:   # only the 64-byte z-runs the rank's beams can ever touch moved
             plan = eng.exchanger.plan
             assert plan is not None and 0 < 8 * plan.runs_out < 0.6 * plan.dense_out
