@@ -144,7 +144,7 @@ class RayTracer:
         return gain
 
     def cbet_solve(self, edep, gain_params, rank=0, world_size=1, group=None, fields=None, gain=None, slabs=False,
-                   force_collectives=False, sparse=False):
+                   force_collectives=False, sparse=False, **slab_options):
         """The CBET iteration, one rank's share (cbet_fixed_point -- or, with slabs=True, cbet_fixed_point_slabs,
         the exchange sized for xGMI -- with this device as the engine): the deposition pass is ADDED into
         `edep` (not reduced here: use allreduce_grid).  Single-rank callers can use the native loop instead:
@@ -153,7 +153,7 @@ class RayTracer:
         engine.force_collectives = force_collectives
         if slabs:
             rep = cbet_fixed_point_slabs(engine, gain_params, self.params.nbeams, self.grid_shape[0], rank, world_size, group,
-                                         sparse=sparse)
+                                         sparse=sparse, **slab_options)      # trace_groups=, balance=
             rep["workspace_bytes"] = engine.slab_bytes()
             plan = engine.exchanger.plan
             rep["exchange"] = {"chunks": engine.exchanger.chunks, "messages": engine.exchanger.messages, "bytes_sent": engine.exchanger.bytes_sent,
@@ -358,6 +358,8 @@ class _DeviceCbetEngine:
     (cbet_cbet_workspace_bytes: 41.2 GB at 256^3 / 60 beams); the slab-owned loop allocates, in begin_slabs, only
     its own beams over the whole grid and all beams over its own x-slab (cbet_cbet_slab_workspace_bytes)."""
 
+    trace_streams = 4     # the beam groups of a field pass rotate over this many streams (a launch's ramp and drain beside its neighbours')
+
     def __init__(self, tracer, edep, gain_params, fields=None, gain=None):
         self.tr, self.edep, self.gp = tracer, edep, gain_params
         self._fields, self._gain = fields, gain
@@ -400,7 +402,7 @@ class _DeviceCbetEngine:
         self.own_fields = torch.zeros((4, b1 - b0) + tr.grid_shape, **f64)
         self.gain_own = torch.zeros((b1 - b0,) + tr.grid_shape, **f64)
         self.gain = self.gain_own            # what a caller gets back: this rank's beams over the whole grid
-        self.s_trace = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        self.s_trace = [torch.cuda.Stream(device=dev) for _ in range(self.trace_streams)]
         self._launches = 0
         tr.tabulate()
         self.ev_ready = torch.cuda.Event()
@@ -420,12 +422,12 @@ class _DeviceCbetEngine:
         self.begin_slab(x0, x1)
 
     def trace_group(self, i0, i1, use_gain, full=True, wait=()):
-        """The field pass of this rank's beams [b0 + i0, b0 + i1) -- one GROUP of a pass -- on the next of two alternating
+        """The field pass of this rank's beams [b0 + i0, b0 + i1) -- one GROUP of a pass -- on the next of the rotating
         trace streams, after the events in `wait` (the gain of these beams having arrived).  Consecutive groups overlap
         (the drain of one launch beside the head of the next), and a finished group can be sent while the next one
         traces.  Returns the event recorded behind the launch."""
         tr = self.tr
-        st = self.s_trace[self._launches % 2]
+        st = self.s_trace[self._launches % len(self.s_trace)]
         self._launches += 1
         st.wait_event(self.ev_ready)
         for ev in wait:
@@ -566,40 +568,55 @@ def _parts(total, world_size):
     return [((r * total) // world_size, ((r + 1) * total) // world_size) for r in range(world_size)]
 
 
-def balanced_slabs(weights, world_size):
+def balanced_slabs(weights, world_size, widest=None):
     """Contiguous plane ranges [(lo, hi)] per rank whose summed `weights` (one per plane of the haloed grid) are as equal as
-    whole planes allow; every rank gets at least one plane while there are enough.  The same deterministic rule on every
-    rank (the weights come out of an all-reduce of integers)."""
+    whole planes allow; every rank gets at least one plane while there are enough.  widest: no slab wider than this many
+    planes (a per-plane constant is added to the weights until that holds: the cut moves towards equal plane counts) --
+    the time of a grouped send/recv is set by its largest message, i.e. by the widest slab, so work balance is bought with
+    link time.  The same deterministic rule on every rank (the weights come out of an all-reduce of integers)."""
     w = np.asarray(weights, dtype=np.float64)
     X = len(w)
     if world_size >= X or not np.isfinite(w).all() or w.sum() <= 0:
         return _parts(X, world_size)
-    cum = np.concatenate([[0.0], np.cumsum(w)])
-    cuts = [0]
-    for r in range(1, world_size):
-        target = cum[-1] * r / world_size
-        x = int(np.searchsorted(cum, target))
-        if x > 0 and abs(cum[x - 1] - target) <= abs(cum[min(x, X)] - target):
-            x -= 1
-        cuts.append(min(max(x, cuts[-1] + 1), X - (world_size - r)))
-    cuts.append(X)
-    return [(cuts[r], cuts[r + 1]) for r in range(world_size)]
+
+    def cut(v):
+        cum = np.concatenate([[0.0], np.cumsum(v)])
+        cuts = [0]
+        for r in range(1, world_size):
+            target = cum[-1] * r / world_size
+            x = int(np.searchsorted(cum, target))
+            if x > 0 and abs(cum[x - 1] - target) <= abs(cum[min(x, X)] - target):
+                x -= 1
+            cuts.append(min(max(x, cuts[-1] + 1), X - (world_size - r)))
+        cuts.append(X)
+        return [(cuts[r], cuts[r + 1]) for r in range(world_size)]
+
+    out = cut(w)
+    if widest is not None:
+        widest = max(int(widest), -(-X // world_size))
+        lam, mean = 0.0, w.mean()
+        for _ in range(40):
+            if max(hi - lo for lo, hi in out) <= widest:
+                break
+            lam = mean * 0.05 if lam == 0.0 else lam * 1.5
+            out = cut(w + lam)
+        else:
+            out = _parts(X, world_size)
+    return out
 
 
 def gain_update_weights(counts):
     """Per-plane cost of the gain update from the number of beams present at each node (`counts`, integer [X][Y][Z], summed
-    over ranks): the pair-once kernel's time splits into a part per cell (presence masks: 2.3 ms of a 256^3 / 60-beam
-    call), a part per present beam (normalise, stage, relax: 5.1 ms) and a part per beam PAIR (4.0 ms) -- timing builds
-    that skip phases, profiles/r3/experiments/gain_kernel.log.  Returns a float64 numpy array [X]."""
+    over ranks).  The pair-once kernel works in runs of 16 cells along z whose cells advance in lockstep, so a run costs what
+    its most crowded cell costs, and that grows with the SQUARE of the beams there (pairs): timed on 8-plane slabs of the
+    256^3 / 60-beam grid, a plane costs 0.048 ms where the runs' maxima average m^2 = 154 and 0.125 ms where they average
+    284 -- 2.6 x for 1.2 x the beams per node -- and ms per plane = 6.2e-4 (mean m^2 - 78) fits to 12 %
+    (scripts/gain_plane_cost.py, profiles/r4/gain_plane_cost.log).  Returns a float64 numpy array [X] (relative weights)."""
     n = counts.to(torch.float64)
-    pairs = n * (n - 1.0) * 0.5
-    s0, s1, s2 = float(n.numel()), float(n.sum()), float(pairs.sum())
-    w = torch.full((n.shape[0],), 2.3 * n[0].numel() / s0, dtype=torch.float64, device=n.device)
-    if s1 > 0:
-        w += 5.1 * n.sum((1, 2)) / s1
-    if s2 > 0:
-        w += 4.0 * pairs.sum((1, 2)) / s2
-    return w.cpu().numpy()
+    X, Y, Z = n.shape
+    pad = (-Z) % 16
+    m = torch.nn.functional.pad(n, (0, pad)).view(X, Y, (Z + pad) // 16, 16).max(-1).values
+    return (m * m - 78.0).clamp_(min=8.0).sum((1, 2)).cpu().numpy()
 
 
 class _SlabExchanger:
@@ -619,12 +636,16 @@ class _SlabExchanger:
     Ranks without beams or planes simply post nothing; every rank walks the beam indices in the same order, so the
     sends and receives of a pair match in order."""
 
-    def __init__(self, device, group, rank, world_size, beams, force_collectives=False):
+    def __init__(self, device, group, rank, world_size, beams, force_collectives=False, emulate=None):
         import torch.distributed as dist
         self.group, self.device, self.rank, self.world, self.beams = group, torch.device(device), rank, world_size, beams
         self.cuda = self.device.type == "cuda"
         self.dist_on = dist.is_available() and dist.is_initialized()
-        self.nccl = self.cuda and self.dist_on and dist.get_backend(group) == "nccl"
+        # emulate(exchanger, sends, recvs): a stand-in for the transport of one grouped send/recv, run on the communication
+        # stream exactly where RCCL's would be (scripts/cbet_rank_share.py: one rank's schedule on one GPU, the peers'
+        # data supplied and the link time priced) -- everything else of the schedule is the product's
+        self.emulate = emulate
+        self.nccl = self.cuda and ((self.dist_on and dist.get_backend(group) == "nccl") or emulate is not None)
         self.force = force_collectives      # one rank: the same send/recv machinery as a self-exchange (RCCL smoke test)
         self.stream = torch.cuda.Stream(device=self.device) if self.nccl else None
         self.solo = world_size == 1
@@ -670,6 +691,12 @@ class _SlabExchanger:
         """One grouped send/recv: `sends` / `recvs` are (tensor view, peer) lists of contiguous views."""
         import torch.distributed as dist
         if not sends and not recvs:
+            return
+        if self.emulate is not None:
+            self.emulate(self, sends, recvs)
+            self.bytes_sent += 8 * sum(t.numel() for t, _ in sends)
+            self.chunks += 1
+            self.messages += len(sends) + len(recvs)
             return
         ops, late = [], []
         for t, peer in sends:
@@ -910,7 +937,7 @@ class _NullContext:
 
 
 def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_size=1, group=None, sparse=False,
-                           trace_groups=4, balance=True):
+                           trace_groups=4, balance=1.0):
     """The CBET fixed-point iteration with storage, exchange and schedule sized for 8 ranks on point-to-point xGMI (SURVEY
     8(f) f1; parity unpinned; same passes and same result as cbet_fixed_point).
 
@@ -918,13 +945,18 @@ def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_s
     owns the x-slab [x_r0, x_r1) of the deposit grid for the gain update.  It STORES only
         its own beams over the whole grid : own_fields [4][nb_r][X][Y][Z], gain_own [nb_r][X][Y][Z]
         all beams over its own slab       : slab_fields [4][nb][x_r][Y][Z], gain_slab [nb][x_r][Y][Z]
-    (cbet_cbet_slab_workspace_bytes_parts).  The slabs are cut by gain-update WORK, not by plane count (balance): after
-    the first (gain-free) field pass every rank counts its beams per node, the counts are all-reduced once and the
-    planes are dealt so that the modelled cost of the update (gain_update_weights) is equal -- the beams cross at the
-    centre, and with equal plane counts the central ranks' update takes twice the outer ranks'.
+    (cbet_cbet_slab_workspace_bytes_parts).  The slabs are cut by gain-update WORK, not only by plane count: after the
+    first (gain-free) field pass every rank counts its beams per node, the counts are all-reduced once and the planes are
+    dealt so that the modelled cost of the update (gain_update_weights) is as equal as the cap `balance` allows -- the beams
+    cross at the centre, and with equal plane counts the central ranks' update takes twice the outer ranks'.  balance = the
+    widest slab allowed, as a multiple of the equal share (1 or False: equal plane counts): a grouped send/recv lasts as
+    long as its largest message, which goes to the widest slab, so a fully work-balanced cut (outer slabs 1.6 x the equal
+    share at 256^3 / 60 beams) lengthens both exchanges by that factor.  At the 64 GB/s per link the exchanges are priced
+    with, that costs more than the balance saves (scripts/cbet_rank_share.py, profiles/r4/cbet_rank_share.log: the
+    slowest rank's iteration 10.4 ms with equal planes, 12-14 ms fully balanced), so the default is the equal cut.
 
-    One pass, pipelined over beam GROUPS (trace_groups of them; engine.trace_group runs them on alternating streams):
-        trace group g  ->  exchange 1 of group g's beams (while group g + 1 traces): my beams' fields over slab s to
+    One pass, pipelined over beam GROUPS (trace_groups of them; engine.trace_group rotates them over its trace streams):
+        trace group g  ->  exchange 1 of group g's beams (while the later groups trace): my beams' fields over slab s to
         rank s, all peers of a beam in one grouped send/recv  ->  [all groups in]  gain update of ALL beams on my slab
         ->  exchange 2, group by group in the order the next pass traces them: the gain of rank q's beams over my
         slab back to q  ->  the next pass's trace of group g starts as soon as ITS gain is in.
@@ -944,7 +976,8 @@ def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_s
     groups = [g for g in _parts(imax, max(1, min(trace_groups, imax))) if g[1] > g[0]]     # beam-INDEX ranges, the same on every rank
     force = getattr(engine, "force_collectives", False)   # one rank, but every collective really runs (RCCL smoke test)
     engine.begin_beams(b0, b1)
-    xch = _SlabExchanger(engine.own_fields.device, group, rank, world_size, beams, force_collectives=force)
+    xch = _SlabExchanger(engine.own_fields.device, group, rank, world_size, beams, force_collectives=force,
+                         emulate=getattr(engine, "emulate_transport", None))
     engine.exchanger = xch
     on_device = engine.own_fields.is_cuda
     cur = (lambda: torch.cuda.current_stream(engine.own_fields.device)) if on_device else None
@@ -976,23 +1009,45 @@ def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_s
     # uses the field arrays as scratch and resets the counters: before the first field pass.)
     support = engine.support_mask() if (sparse and hasattr(engine, "support_mask") and (world_size > 1 or force)) else None
     slabs, plan = None, None
-    gain_ev = [None] * len(groups)
+    G = len(groups)
+    gain_ev = [None] * G
+    owed = []           # groups whose gain of the previous pass has not been sent back yet (it goes out between this pass's traces)
+    updated = None
+    # ONE in-order channel carries both exchanges (RCCL serialises the calls of a communicator), so the order they are
+    # enqueued in is the schedule: behind the update the gain of ALL groups goes back, group by group in the order the next
+    # pass traces them and before the host has even looked at the convergence scalars; group k of the next pass starts
+    # tracing when ITS gain is in (k + 1 calls into the exchange) and the groups overlap on the rotating trace streams;
+    # a group's fields are enqueued right behind its trace and travel while the later groups trace.  (Measured with the
+    # kernel trace of scripts/cbet_rank_share.py: sending a group's gain just ahead of its own trace, interleaved with
+    # the fields of earlier groups, chains trace -> fields -> gain -> trace through the one channel and stretches the
+    # trace phase from 4.5 to 9 ms.)  HEAD = groups whose gain goes back before the scalars are looked at, LAG = groups
+    # between a trace and the enqueueing of its fields.
+    HEAD, LAG = G, 0
+
+    def send_gain(k):
+        i0, i1 = groups[k]
+        return xch.gain_back(engine.gain_slab, engine.gain_own, i0, i1, after=(updated,))
+
     rep = {"passes": 0, "converged": False, "change": float("inf")}
     for it in range(gain_params.max_passes):
         full = it < gain_params.direction_passes
         comps = range(4) if full else range(1)    # after the direction-building passes only the energy field moves
-        traced = []
-        for g, (i0, i1) in enumerate(groups):
+        traced = [None] * G
+        for k, (i0, i1) in enumerate(groups):
+            if k in owed:
+                gain_ev[k] = send_gain(k)
+                owed.remove(k)
             j0, j1 = min(i0, nbr), min(i1, nbr)
-            traced.append(engine.trace_group(j0, j1, it > 0, full, wait=(gain_ev[g],)) if j1 > j0 else None)
-            if slabs is not None and plan is None:
-                xch.fields_out(engine.own_fields, engine.slab_fields, i0, i1, comps, after=(traced[g],))
+            if j1 > j0:
+                traced[k] = engine.trace_group(j0, j1, it > 0, full, wait=(gain_ev[k],))
+            if slabs is not None and plan is None and k >= LAG:
+                xch.fields_out(engine.own_fields, engine.slab_fields, *groups[k - LAG], comps, after=(traced[k - LAG],))
         if slabs is None:
             # first pass: the beams' footprints are known now -- cut the slabs, allocate them, then send everything
             wait_here(traced)
-            if balance and world_size > 1:
+            if balance and float(balance) > 1.0 and world_size > 1:
                 counts = all_reduce_host_staged(engine.presence_counts())
-                slabs = balanced_slabs(gain_update_weights(counts), world_size)
+                slabs = balanced_slabs(gain_update_weights(counts), world_size, widest=float(balance) * nx_halo / world_size)
                 del counts
             else:
                 slabs = _parts(nx_halo, world_size)
@@ -1002,31 +1057,37 @@ def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_s
                 plan = SegmentPlan(support, beams, slabs, rank, world_size, group, engine.slab_fields.device)
                 support = None
                 xch.use_plan(plan)
-            if plan is None:
-                for g, (i0, i1) in enumerate(groups):
-                    xch.fields_out(engine.own_fields, engine.slab_fields, i0, i1, comps, after=(traced[g],))
+            first = 0
+        else:
+            first = G - LAG
         if plan is not None:
             xch.run_sparse(engine.own_fields, lambda s_: (slice(0, len(comps)), slice(None), slice(*slabs[s_])),
                            engine.slab_fields, lambda q: (slice(0, len(comps)), slice(*beams[q])), True,
                            ncomp=len(comps), after=traced)
+        else:
+            for k in range(first, G):
+                xch.fields_out(engine.own_fields, engine.slab_fields, *groups[k], comps, after=(traced[k],))
         wait_here([xch.fence()])                     # every beam's fields over my slab are in
-        ch = all_reduce_host_staged(engine.update_gain_slab(not full))
+        ch = engine.update_gain_slab(not full)
         updated = mark()
-        # the gain of rank q's beams over my slab -> rank q; my beams' gain over slab s <- rank s: group by group, in the
-        # order the next pass traces them (and before the host learns whether there is a next pass: the deposition
-        # pass needs the new gain as well)
+        # the gain of rank q's beams over my slab -> rank q; my beams' gain over slab s <- rank s.  It is due whatever the
+        # convergence scalars say (the deposition pass needs the new gain too): the head goes out now
         if plan is not None:
             ev = xch.run_sparse(engine.gain_slab, lambda q: (slice(*beams[q]),),
                                 engine.gain_own, lambda s_: (slice(None), slice(*slabs[s_])), False, after=(updated,))
-            gain_ev = [ev] * len(groups)
+            gain_ev, owed = [ev] * G, []
         else:
-            gain_ev = [xch.gain_back(engine.gain_slab, engine.gain_own, i0, i1, after=(updated,)) for i0, i1 in groups]
-        ch = _agree(ch, group, world_size)
+            for k in range(HEAD):
+                gain_ev[k] = send_gain(k)
+            owed = list(range(HEAD, G))
+        ch = _agree(all_reduce_host_staged(ch), group, world_size)
         rep["passes"] = it + 1
         rep["change"] = float(ch[0] / ch[1]) if float(ch[1]) > 0 else 0.0
         if rep["change"] < gain_params.tolerance:
             rep["converged"] = True
             break
+    for k in list(owed):                              # no further pass: the rest of the gain goes back now
+        gain_ev[k] = send_gain(k)
     wait_here(gain_ev)
     beam_gain = engine.deposit_beams()
     if world_size > 1 or force:

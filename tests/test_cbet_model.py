@@ -174,12 +174,13 @@ def test_balanced_slabs_rule():
     c8 = balanced_slabs(w, 8)
     assert c8[0][1] - c8[0][0] > 2 * (c8[3][1] - c8[3][0])          # outer slabs are much wider than central ones
     assert balanced_slabs(np.zeros(10), 4) == _parts(10, 4) and balanced_slabs(np.ones(3), 5) == _parts(3, 5)
-    # the cost model: cells, present beams, beam pairs
-    cnt = torch.zeros((4, 3, 3), dtype=torch.int32)
-    cnt[1] = 2
-    cnt[2] = 4
+    # the cost model: a 16-cell z-run costs what its most crowded cell costs, ~ the square of the beams there
+    cnt = torch.zeros((4, 3, 40), dtype=torch.int32)
+    cnt[1] = 10
+    cnt[2, :, 5] = 20          # one crowded cell per row: its whole run is dear, the other runs of the plane are not
     gw = gain_update_weights(cnt)
-    assert gw[0] == gw[3] and gw[2] > gw[1] > gw[0] > 0 and abs(gw.sum() - (2.3 + 5.1 + 4.0)) < 1e-9
+    runs = 3 * 3               # rows x z-runs of 16 (40 -> 48 padded)
+    assert gw[0] == gw[3] == 8.0 * runs and gw[1] == (100 - 78.0) * runs and gw[2] == 3 * (400 - 78.0) + 3 * 2 * 8.0
 
 
 class _OracleEngine:
@@ -302,7 +303,9 @@ def _solve(rank, world, group=None, slabs=False, sparse=False):
     eng = _OracleEngine(O, api, cfg, O.gain_default(), bn[BEAMS].copy(), ne3d, kap, len(BEAMS))
     gp = api.default_gain_params(relax=1.0, tolerance=1e-5, max_passes=8)
     if slabs:
-        rep = cbet_fixed_point_slabs(eng, gp, len(BEAMS), N + 2, rank, world, group, sparse=sparse)
+        # (three ranks: slabs cut by gain-update work, at most 1.5 x the equal share wide, in three trace groups; else the defaults)
+        opts = dict(balance=1.5, trace_groups=3) if world == 3 else {}
+        rep = cbet_fixed_point_slabs(eng, gp, len(BEAMS), N + 2, rank, world, group, sparse=sparse, **opts)
         eng.gain = eng.gain_own.numpy()          # this rank's beams over the whole grid
         # what the rank stored: (5 nb_r + 5 nb / W) grids = 10 nb / W: the whole problem's 5 nb at two ranks, less beyond
         full = (N + 2) ** 3
