@@ -412,3 +412,43 @@ def test_slab_owned_iteration_equals_unsharded(tmp_path, api, oracle, world, spa
     if not sparse:     # (the sparse exchange delivers a beam's gain inside its footprint only -- all its rays can read)
         assert np.abs(got["gain"] - gain[b0:b1]).max() < 1e-9 * np.abs(gain).max()
     assert np.abs(got["beam_gain"] - rep["beam_gain"]).max() < 1e-9 * np.abs(rep["beam_gain"]).max()
+
+
+def test_exchanger_messages_are_contiguous_views_grouped_per_beam():
+    """tracer._SlabExchanger without a process group, its transport replaced by a recorder (the hook scripts/cbet_rank_share.py
+    uses): for rank 1 of 3 every grouped call must hold the messages of BOTH peers of one beam index, every message must be
+    a contiguous view of the array it leaves or lands in (nothing is staged), and the own part must be copied locally."""
+    from cbet_raytracing_3d_amd.tracer import _SlabExchanger, _parts
+    nb, X, Y, Z, W, rank = 7, 10, 3, 4, 3, 1
+    beams, slabs = _parts(nb, W), _parts(X, W)
+    (b0, b1), (x0, x1) = beams[rank], slabs[rank]
+    own = torch.arange(4 * (b1 - b0) * X * Y * Z, dtype=torch.float64).view(4, b1 - b0, X, Y, Z)
+    slab = torch.zeros(4, nb, x1 - x0, Y, Z, dtype=torch.float64)
+    calls = []
+    xch = _SlabExchanger("cpu", None, rank, W, beams, emulate=lambda x, s, r: calls.append((s, r)))
+    xch.set_slabs(slabs)
+    imax = max(q1 - q0 for q0, q1 in beams)
+    assert xch.fields_out(own, slab, 0, imax, range(4)) is None          # no device: no event
+    assert len(calls) == imax and xch.chunks == imax
+    for i, (sends, recvs) in enumerate(calls):
+        mine = i < b1 - b0
+        assert sorted({p for _, p in sends}) == ([0, 2] if mine else [])
+        assert len(sends) == (8 if mine else 0)                           # 2 peers x 4 components
+        for t, peer in sends:
+            xs0, xs1 = slabs[peer]
+            assert t.is_contiguous() and t.shape == (xs1 - xs0, Y, Z) and t.untyped_storage().data_ptr() == own.untyped_storage().data_ptr()
+        for t, peer in recvs:
+            q0, q1 = beams[peer]
+            assert i < q1 - q0 and t.is_contiguous() and t.shape == (x1 - x0, Y, Z)
+            assert t.untyped_storage().data_ptr() == slab.untyped_storage().data_ptr()
+    assert torch.equal(slab[:, b0:b1], own[:, :, x0:x1])                  # the own part never travels
+    assert xch.bytes_sent == 8 * 4 * (b1 - b0) * (X - (x1 - x0)) * Y * Z and xch.staging_bytes() == 0
+    # exchange 2: the gain of the peers' beams over my slab out, my beams' gain over their slabs in
+    calls.clear()
+    gain_slab = torch.arange(nb * (x1 - x0) * Y * Z, dtype=torch.float64).view(nb, x1 - x0, Y, Z)
+    gain_own = torch.zeros(b1 - b0, X, Y, Z, dtype=torch.float64)
+    xch.gain_back(gain_slab, gain_own, 0, imax)
+    assert len(calls) == imax
+    sent = sum(t.numel() for s_, _ in calls for t, _ in s_)
+    assert sent == (nb - (b1 - b0)) * (x1 - x0) * Y * Z
+    assert torch.equal(gain_own[:, x0:x1], gain_slab[b0:b1])
