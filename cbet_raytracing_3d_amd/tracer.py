@@ -153,7 +153,7 @@ class RayTracer:
         engine.force_collectives = force_collectives
         if slabs:
             rep = cbet_fixed_point_slabs(engine, gain_params, self.params.nbeams, self.grid_shape[0], rank, world_size, group,
-                                         sparse=sparse, **slab_options)      # trace_groups=, balance=
+                                         sparse=sparse, **slab_options)      # trace_groups=, slab_layout=
             rep["workspace_bytes"] = engine.slab_bytes()
             plan = engine.exchanger.plan
             rep["exchange"] = {"chunks": engine.exchanger.chunks, "messages": engine.exchanger.messages, "bytes_sent": engine.exchanger.bytes_sent,
@@ -408,18 +408,19 @@ class _DeviceCbetEngine:
         self.ev_ready = torch.cuda.Event()
         self.ev_ready.record(torch.cuda.current_stream(dev))
 
-    def begin_slab(self, x0, x1):
-        """All beams over this rank's planes [x0, x1) (what its gain update reads and writes)."""
+    def begin_slab(self, pieces):
+        """All beams over this rank's planes (what its gain update reads and writes): one packed array pair per PIECE
+        [(lo, hi), ...] of its share of the deposit grid -- one x-slab, or two (slab_layout "paired")."""
         tr = self.tr
         nb, gs = tr.params.nbeams, tr.grid_shape
-        self.x0, self.x1 = x0, x1
+        self.pieces = [tuple(pc) for pc in pieces]
         f64 = dict(dtype=torch.float64, device=tr.device)
-        self.slab_fields = torch.zeros((4, nb, x1 - x0) + gs[1:], **f64)
-        self.gain_slab = torch.zeros((nb, x1 - x0) + gs[1:], **f64)
+        self.slab_fields = [torch.zeros((4, nb, hi - lo) + gs[1:], **f64) for lo, hi in self.pieces]
+        self.gain_slab = [torch.zeros((nb, hi - lo) + gs[1:], **f64) for lo, hi in self.pieces]
 
     def begin_slabs(self, b0, b1, x0, x1):
         self.begin_beams(b0, b1)
-        self.begin_slab(x0, x1)
+        self.begin_slab([(x0, x1)])
 
     def trace_group(self, i0, i1, use_gain, full=True, wait=()):
         """The field pass of this rank's beams [b0 + i0, b0 + i1) -- one GROUP of a pass -- on the next of the rotating
@@ -453,7 +454,7 @@ class _DeviceCbetEngine:
     def slab_bytes(self):
         """Device bytes this rank's slab loop holds: the arrays of begin_beams / begin_slab and, for sparse exchanges, the
         staging buffers and segment lists (the dense exchange sends from and receives into the arrays themselves)."""
-        arrays = 8 * sum(t.numel() for t in (self.own_fields, self.gain_own, self.slab_fields, self.gain_slab))
+        arrays = 8 * sum(t.numel() for t in [self.own_fields, self.gain_own] + list(self.slab_fields) + list(self.gain_slab))
         xch = getattr(self, "exchanger", None)
         if xch is None:
             return arrays
@@ -488,11 +489,29 @@ class _DeviceCbetEngine:
         return self.own_fields
 
     def update_gain_slab(self, frozen=False):
+        """The gain update of all beams over this rank's pieces; a second piece runs on a side stream beside the first (two
+        small launches one after the other would each pay their own ramp and drain)."""
         self.change.zero_()
-        if self.x1 > self.x0:
-            stream = torch.cuda.current_stream(self.tr.device).cuda_stream
-            api.gain_field_packed(self.slab_fields, None, self.gain_slab, self.gain_slab, self.change, self.x0, self.x1,
-                                  self.tr.params, _frozen(self.gp, frozen), self.tr.ctx, stream)
+        cur = torch.cuda.current_stream(self.tr.device)
+        gp = _frozen(self.gp, frozen)
+        side_done = []
+        for k, ((lo, hi), fields, gain) in enumerate(zip(self.pieces, self.slab_fields, self.gain_slab)):
+            if hi <= lo:
+                continue
+            if k == 0:
+                api.gain_field_packed(fields, None, gain, gain, self.change, lo, hi, self.tr.params, gp, self.tr.ctx, cur.cuda_stream)
+            else:
+                if not hasattr(self, "s_side"):
+                    self.s_side = torch.cuda.Stream(device=self.tr.device)
+                ready = torch.cuda.Event()
+                ready.record(cur)                      # (behind the zeroing of `change` and the arrival fence)
+                self.s_side.wait_event(ready)
+                api.gain_field_packed(fields, None, gain, gain, self.change, lo, hi, self.tr.params, gp, self.tr.ctx, self.s_side.cuda_stream)
+                ev = torch.cuda.Event()
+                ev.record(self.s_side)
+                side_done.append(ev)
+        for ev in side_done:
+            cur.wait_event(ev)
         return self.change
 
     def deposit_beams(self):
@@ -605,6 +624,24 @@ def balanced_slabs(weights, world_size, widest=None):
     return out
 
 
+def slab_pieces(layout, nx_halo, world_size, weights=None):
+    """Which planes of the deposit grid each rank's gain update owns: [[(lo, hi), ...] per rank].
+    "equal"  : one x-slab per rank, equal plane counts (the beams cross at the centre: the central ranks' update takes
+               twice the outer ranks');
+    "paired" : the grid is cut into 2 W equal blocks and rank r owns block r AND block W + r -- one from the left half
+               counted from the edge, one from the right half counted from the centre, i.e. a light and a heavy one: the work
+               evens out (modelled cost spread 1.53 -> 1.13 at 256^3 / 60 beams / 8 ranks) while every message keeps the
+               same size, so no link carries more than another (twice the messages, half as long);
+    a number > 1 : one slab per rank cut by the modelled gain-update cost `weights`, none wider than that multiple of the
+               equal share (balanced_slabs) -- balances better and lengthens every grouped call by the widest slab."""
+    if layout == "paired" and world_size > 1:
+        blocks = _parts(nx_halo, 2 * world_size)
+        return [[b for b in (blocks[r], blocks[world_size + r]) if b[1] > b[0]] or [(0, 0)] for r in range(world_size)]
+    if isinstance(layout, (int, float)) and not isinstance(layout, bool) and float(layout) > 1.0 and world_size > 1 and weights is not None:
+        return [[pc] for pc in balanced_slabs(weights, world_size, widest=float(layout) * nx_halo / world_size)]
+    return [[pc] for pc in _parts(nx_halo, world_size)]
+
+
 def gain_update_weights(counts):
     """Per-plane cost of the gain update from the number of beams present at each node (`counts`, integer [X][Y][Z], summed
     over ranks).  The pair-once kernel works in runs of 16 cells along z whose cells advance in lockstep, so a run costs what
@@ -655,8 +692,9 @@ class _SlabExchanger:
         self.send_buf = self.recv_buf = None    # sparse exchanges only
         self.chunks = self.messages = self.bytes_sent = 0
 
-    def set_slabs(self, slabs):
-        self.slabs = slabs
+    def set_slabs(self, pieces):
+        """pieces[r] = the plane ranges [(lo, hi), ...] rank r's gain update owns (slab_pieces)."""
+        self.slabs = pieces
 
     def staging_bytes(self):
         if self.send_buf is None or self.send_buf.device != self.device:
@@ -718,49 +756,49 @@ class _SlabExchanger:
         self.messages += len(ops)
 
     def fields_out(self, own, slab, i0, i1, comps, after=()):
-        """Exchange 1 for the beams with index [i0, i1) of every rank: my beams' fields over slab s -> rank s, rank q's
-        beams over my slab <- rank q, component by component of `comps`.  own: [4][my beams][X][Y][Z], slab:
-        [4][all beams][my planes][Y][Z]."""
-        rank, beams, slabs = self.rank, self.beams, self.slabs
+        """Exchange 1 for the beams with index [i0, i1) of every rank: my beams' fields over rank s's pieces -> rank s, rank
+        q's beams over my pieces <- rank q, component by component of `comps`.  own: [4][my beams][X][Y][Z]; slab: one
+        [4][all beams][piece planes][Y][Z] per piece of mine."""
+        rank, beams, pieces = self.rank, self.beams, self.slabs
         b0, b1 = beams[rank]
-        x0, x1 = slabs[rank]
         with self._enter(after):
             for i in range(i0, i1):
                 sends, recvs = [], []
                 mine = i < b1 - b0
                 for s_ in self.peers:
-                    xs0, xs1 = slabs[s_]
-                    if mine and xs1 > xs0:
-                        sends += [(own[c, i, xs0:xs1], s_) for c in comps]
+                    if mine:
+                        sends += [(own[c, i, lo:hi], s_) for lo, hi in pieces[s_] if hi > lo for c in comps]
                     q0, q1 = beams[s_]
-                    if i < q1 - q0 and x1 > x0:
-                        recvs += [(slab[c, q0 + i], s_) for c in comps]
-                if mine and x1 > x0 and not (self.solo and self.force):
-                    for c in comps:
-                        slab[c, b0 + i].copy_(own[c, i, x0:x1])       # the own part never travels
+                    if i < q1 - q0:
+                        recvs += [(slab[k][c, q0 + i], s_) for k, (lo, hi) in enumerate(pieces[rank]) if hi > lo for c in comps]
+                if mine and not (self.solo and self.force):
+                    for k, (lo, hi) in enumerate(pieces[rank]):
+                        for c in comps:
+                            if hi > lo:
+                                slab[k][c, b0 + i].copy_(own[c, i, lo:hi])       # the own part never travels
                 self._batch(sends, recvs)
         return self._leave()
 
     def gain_back(self, gain_slab, gain_own, i0, i1, after=()):
-        """Exchange 2 for the beams with index [i0, i1): the new gain of rank q's beams over my slab -> rank q, my beams'
-        gain over slab s <- rank s.  gain_slab: [all beams][my planes][Y][Z], gain_own: [my beams][X][Y][Z].  Returns the
-        event behind it: the next pass's trace of these beams waits for it."""
-        rank, beams, slabs = self.rank, self.beams, self.slabs
+        """Exchange 2 for the beams with index [i0, i1): the new gain of rank q's beams over my pieces -> rank q, my beams'
+        gain over rank s's pieces <- rank s.  gain_slab: one [all beams][piece planes][Y][Z] per piece of mine; gain_own:
+        [my beams][X][Y][Z].  Returns the event behind it: the next pass's trace of these beams waits for it."""
+        rank, beams, pieces = self.rank, self.beams, self.slabs
         b0, b1 = beams[rank]
-        x0, x1 = slabs[rank]
         with self._enter(after):
             for i in range(i0, i1):
                 sends, recvs = [], []
                 mine = i < b1 - b0
                 for q in self.peers:
                     q0, q1 = beams[q]
-                    if i < q1 - q0 and x1 > x0:
-                        sends.append((gain_slab[q0 + i], q))
-                    xs0, xs1 = slabs[q]
-                    if mine and xs1 > xs0:
-                        recvs.append((gain_own[i, xs0:xs1], q))
-                if mine and x1 > x0 and not (self.solo and self.force):
-                    gain_own[i, x0:x1].copy_(gain_slab[b0 + i])
+                    if i < q1 - q0:
+                        sends += [(gain_slab[k][q0 + i], q) for k, (lo, hi) in enumerate(pieces[rank]) if hi > lo]
+                    if mine:
+                        recvs += [(gain_own[i, lo:hi], q) for lo, hi in pieces[q] if hi > lo]
+                if mine and not (self.solo and self.force):
+                    for k, (lo, hi) in enumerate(pieces[rank]):
+                        if hi > lo:
+                            gain_own[i, lo:hi].copy_(gain_slab[k][b0 + i])
                 self._batch(sends, recvs)
         return self._leave()
 
@@ -937,23 +975,25 @@ class _NullContext:
 
 
 def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_size=1, group=None, sparse=False,
-                           trace_groups=4, balance=1.0):
+                           trace_groups=4, slab_layout="equal"):
     """The CBET fixed-point iteration with storage, exchange and schedule sized for 8 ranks on point-to-point xGMI (SURVEY
     8(f) f1; parity unpinned; same passes and same result as cbet_fixed_point).
 
     Rank r traces WHOLE beams [b_r0, b_r1) -- their four fields are complete on r without any reduction -- and
-    owns the x-slab [x_r0, x_r1) of the deposit grid for the gain update.  It STORES only
+    owns some planes of the deposit grid for the gain update (its PIECES, slab_pieces).  It STORES only
         its own beams over the whole grid : own_fields [4][nb_r][X][Y][Z], gain_own [nb_r][X][Y][Z]
-        all beams over its own slab       : slab_fields [4][nb][x_r][Y][Z], gain_slab [nb][x_r][Y][Z]
-    (cbet_cbet_slab_workspace_bytes_parts).  The slabs are cut by gain-update WORK, not only by plane count: after the
-    first (gain-free) field pass every rank counts its beams per node, the counts are all-reduced once and the planes are
-    dealt so that the modelled cost of the update (gain_update_weights) is as equal as the cap `balance` allows -- the beams
-    cross at the centre, and with equal plane counts the central ranks' update takes twice the outer ranks'.  balance = the
-    widest slab allowed, as a multiple of the equal share (1 or False: equal plane counts): a grouped send/recv lasts as
-    long as its largest message, which goes to the widest slab, so a fully work-balanced cut (outer slabs 1.6 x the equal
-    share at 256^3 / 60 beams) lengthens both exchanges by that factor.  At the 64 GB/s per link the exchanges are priced
-    with, that costs more than the balance saves (scripts/cbet_rank_share.py, profiles/r4/cbet_rank_share.log: the
-    slowest rank's iteration 10.4 ms with equal planes, 12-14 ms fully balanced), so the default is the equal cut.
+        all beams over its own pieces     : per piece slab_fields [4][nb][x_p][Y][Z], gain_slab [nb][x_p][Y][Z]
+    (cbet_cbet_slab_workspace_bytes_parts).  slab_layout says which planes.  "equal" (default): one x-slab per rank, equal
+    plane counts -- the beams cross at the centre, a central plane's update costs twice an outer one's, and the central
+    ranks' update takes 2.4 ms against the outer ranks' 1.2 (256^3 / 60 beams / 8 ranks) while everybody waits for it.
+    "paired": every rank owns one block of the grid's left half counted from the edge and one of its right half counted
+    from the centre -- a light and a heavy one, messages of equal size (twice as many, half as long): measured 1.9-2.25 ms
+    on every rank (two 16-plane launches each pay their ramp and drain), i.e. 0.15 ms off the slowest.  A number > 1: one
+    slab per rank cut by the modelled cost (gain_update_weights from the beams counted per node after the first field
+    pass, all-reduced once), none wider than that multiple of the equal share: 1.7-2.0 ms everywhere when unlimited, but a
+    grouped send/recv lasts as long as its largest message, which goes to the widest slab (1.6 x), and at the 64 GB/s the
+    links are priced with that costs more than the balance saves.  Neither moves the iteration outside the noise of the
+    one-GPU emulation (scripts/cbet_rank_share.py, profiles/r4/cbet_rank_share.log); the simplest stays the default.
 
     One pass, pipelined over beam GROUPS (trace_groups of them; engine.trace_group rotates them over its trace streams):
         trace group g  ->  exchange 1 of group g's beams (while the later groups trace): my beams' fields over slab s to
@@ -965,7 +1005,7 @@ def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_s
     0.9 GB + 0.9 GB in every later one (energy field only).  sparse=True: the un-pipelined exchange of only the z-runs
     inside the beams' footprints (SegmentPlan; exact; does not pay for this physics, see profiles/r3/cbet_rank_share.log).
     `engine`: begin_beams(b0, b1); trace_group(i0, i1, use_gain, full, wait) -> event or None; presence_counts() ->
-    integer [X][Y][Z]; begin_slab(x0, x1); attributes own_fields, gain_own, slab_fields, gain_slab;
+    integer [X][Y][Z]; begin_slab(pieces); attributes own_fields, gain_own, slab_fields, gain_slab (lists, one per piece);
     update_gain_slab(frozen) -> tensor {sum |dK|, sum |K|} over the slab; deposit_beams() -> beam_gain.  The
     deposition grid is left un-reduced (allreduce_grid / reduce_scatter_grid)."""
     import torch.distributed as dist
@@ -1008,7 +1048,7 @@ def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_s
     # Exact, but it does not pay for this physics: 73 % of the nodes are inside a beam's footprint.  (The footprint pass
     # uses the field arrays as scratch and resets the counters: before the first field pass.)
     support = engine.support_mask() if (sparse and hasattr(engine, "support_mask") and (world_size > 1 or force)) else None
-    slabs, plan = None, None
+    slabs, pieces, plan = None, None, None
     G = len(groups)
     gain_ev = [None] * G
     owed = []           # groups whose gain of the previous pass has not been sent back yet (it goes out between this pass's traces)
@@ -1045,16 +1085,18 @@ def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_s
         if slabs is None:
             # first pass: the beams' footprints are known now -- cut the slabs, allocate them, then send everything
             wait_here(traced)
-            if balance and float(balance) > 1.0 and world_size > 1:
+            layout = "equal" if support is not None else slab_layout     # (the sparse plan is written for one slab per rank)
+            weights = None
+            if isinstance(layout, (int, float)) and not isinstance(layout, bool) and float(layout) > 1.0 and world_size > 1:
                 counts = all_reduce_host_staged(engine.presence_counts())
-                slabs = balanced_slabs(gain_update_weights(counts), world_size, widest=float(balance) * nx_halo / world_size)
+                weights = gain_update_weights(counts)
                 del counts
-            else:
-                slabs = _parts(nx_halo, world_size)
-            engine.begin_slab(*slabs[rank])
-            xch.set_slabs(slabs)
+            pieces = slab_pieces(layout, nx_halo, world_size, weights)
+            slabs = [pcs[0] for pcs in pieces]                            # (what the sparse plan indexes by)
+            engine.begin_slab(pieces[rank])
+            xch.set_slabs(pieces)
             if support is not None:
-                plan = SegmentPlan(support, beams, slabs, rank, world_size, group, engine.slab_fields.device)
+                plan = SegmentPlan(support, beams, slabs, rank, world_size, group, engine.slab_fields[0].device)
                 support = None
                 xch.use_plan(plan)
             first = 0
@@ -1062,7 +1104,7 @@ def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_s
             first = G - LAG
         if plan is not None:
             xch.run_sparse(engine.own_fields, lambda s_: (slice(0, len(comps)), slice(None), slice(*slabs[s_])),
-                           engine.slab_fields, lambda q: (slice(0, len(comps)), slice(*beams[q])), True,
+                           engine.slab_fields[0], lambda q: (slice(0, len(comps)), slice(*beams[q])), True,
                            ncomp=len(comps), after=traced)
         else:
             for k in range(first, G):
@@ -1073,7 +1115,7 @@ def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_s
         # the gain of rank q's beams over my slab -> rank q; my beams' gain over slab s <- rank s.  It is due whatever the
         # convergence scalars say (the deposition pass needs the new gain too): the head goes out now
         if plan is not None:
-            ev = xch.run_sparse(engine.gain_slab, lambda q: (slice(*beams[q]),),
+            ev = xch.run_sparse(engine.gain_slab[0], lambda q: (slice(*beams[q]),),
                                 engine.gain_own, lambda s_: (slice(None), slice(*slabs[s_])), False, after=(updated,))
             gain_ev, owed = [ev] * G, []
         else:
@@ -1095,7 +1137,7 @@ def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_s
     bg = beam_gain.cpu().numpy().copy()
     rep["beam_gain"] = bg
     rep["imbalance"] = float(abs(bg.sum()) / np.abs(bg).sum()) if np.abs(bg).sum() > 0 else 0.0
-    rep["slabs"] = slabs
+    rep["slabs"] = pieces
     rep["groups"] = groups
     return rep
 

@@ -49,7 +49,7 @@ nbr, xr = b1 - b0, x1 - x0
 want = api.cbet_slab_workspace_bytes_parts(p, nbr, xr, 0)
 eng = T._DeviceCbetEngine(tr, tr.new_grid(), gp)
 eng.begin_beams(b0, b1)
-eng.begin_slab(x0, x1)
+eng.begin_slab([(x0, x1)])
 torch.cuda.synchronize()
 after_arrays = in_use()
 print("rank arrays: beams [%d,%d) over the whole grid + all beams over planes [%d,%d): formula %.2f GB, engine holds %.2f GB, device memory grew by %.2f GB"
@@ -73,17 +73,17 @@ print("first field pass (four components, no gain) of %d beams: %.1f ms, %.3e ra
 # the peers' beams over my slab: stand-ins dealt from my own beams
 for q in range(nb):
     if not (b0 <= q < b1):
-        eng.slab_fields[:, q].copy_(eng.own_fields[:, (q * 7 + 3) % nbr, x0:x1])
+        eng.slab_fields[0][:, q].copy_(eng.own_fields[:, (q * 7 + 3) % nbr, x0:x1])
 for i in range(nbr):
-    eng.slab_fields[:, b0 + i].copy_(eng.own_fields[:, i, x0:x1])
-keep_e = eng.slab_fields[0].clone()                # the raw energy field (the update normalises in place)
+    eng.slab_fields[0][:, b0 + i].copy_(eng.own_fields[:, i, x0:x1])
+keep_e = eng.slab_fields[0][0].clone()                # the raw energy field (the update normalises in place)
 t_up0 = timed(lambda: eng.update_gain_slab(False))
 print("slab gain update, directions built (%d beams x %d planes): %.1f ms" % (nb, xr, t_up0))
 for i in range(nbr):                               # my beams' gain over my own slab; elsewhere it stays zero (the peers' part)
-    eng.gain_own[i, x0:x1].copy_(eng.gain_slab[b0 + i])
+    eng.gain_own[i, x0:x1].copy_(eng.gain_slab[0][b0 + i])
 t_field = min(timed(lambda: cur.wait_event(eng.trace_group(0, nbr, True, False))) for _ in range(2))
 c = tr.counters(reset=True)
-eng.slab_fields[0].copy_(keep_e)
+eng.slab_fields[0][0].copy_(keep_e)
 t_up = timed(lambda: eng.update_gain_slab(True))
 peak = in_use()
 print("energy-field pass of %d beams with gain: %.1f ms (%.3e ray-steps/s); slab gain update, directions frozen: %.1f ms" % (nbr, t_field, c.ray_steps / 2 / (t_field * 1e-3), t_up))

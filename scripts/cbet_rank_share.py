@@ -12,7 +12,7 @@ stand-in for it (`emulate`): on the communication stream, exactly where RCCL's g
 Kernels, copies, stream order and host round trips are real; only the link time is a model, and it is stated.
 The slabs are cut by gain-update work from the reference solve's beam counts, as the loop cuts them.
 
-usage: python scripts/cbet_rank_share.py [W=8] [n=256] [link GB/s per direction per peer = 64] [trace groups = 4] [ranks = 0,3,7] [widest slab = 1.0 x the equal share]
+usage: python scripts/cbet_rank_share.py [W=8] [n=256] [link GB/s per direction per peer = 64] [trace groups = 4] [ranks = 0,3,7] [slab layout = equal | paired | a number > 1]
 """
 import os
 import sys
@@ -31,7 +31,8 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 LINK = float(sys.argv[3]) if len(sys.argv) > 3 else 64.0      # GB/s per direction per peer link, what RCCL send/recv is assumed to sustain
 GROUPS = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 RANKS = [int(x) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 else sorted({0, W // 2 - 1 if W > 1 else 0, W - 1})
-BALANCE = float(sys.argv[6]) if len(sys.argv) > 6 else 1.0   # widest slab allowed, as a multiple of the equal share
+LAYOUT = sys.argv[6] if len(sys.argv) > 6 else "equal"        # tracer.slab_pieces: "paired", "equal", or the widest slab of a work-balanced cut (x the equal share)
+LAYOUT = LAYOUT if LAYOUT in ("paired", "equal") else float(LAYOUT)
 CALL_US = 15.0                                                 # fixed cost of one grouped send/recv (launch + handshake)
 nb = 60
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -95,11 +96,11 @@ print("single GPU, one iteration: energy-field pass %.2f ms + gain update %.2f m
 counts = (energy != 0).sum(0).to(torch.int32)
 weights = T.gain_update_weights(counts)
 beams = T._parts(nb, W)
-slabs_eq, slabs_bal, slabs_cap = T._parts(X, W), T.balanced_slabs(weights, W), T.balanced_slabs(weights, W, widest=BALANCE * X / W)
-spread = lambda cut: max(weights[a:b].sum() for a, b in cut) / (weights.sum() / W)
-print("slabs by plane count:        ", " ".join("%d" % (b - a) for a, b in slabs_eq), " (modelled gain-update cost, max/mean: %.2f)" % spread(slabs_eq))
-print("slabs by gain-update work:   ", " ".join("%d" % (b - a) for a, b in slabs_bal), " (%.2f)" % spread(slabs_bal))
-print("... no slab wider than %.2f x:" % BALANCE, " ".join("%d" % (b - a) for a, b in slabs_cap), " (%.2f)  <- what the loop cuts" % spread(slabs_cap))
+spread = lambda pcs: max(sum(weights[a:b].sum() for a, b in p_) for p_ in pcs) / (weights.sum() / W)
+show = lambda pcs: " ".join("+".join("%d" % (b - a) for a, b in p_) for p_ in pcs)
+for name, lay in (("one equal slab per rank", "equal"), ("paired blocks (edge + centre)", "paired"), ("one slab by gain-update work", 9.0), ("... none wider than 1.15 x", 1.15)):
+    pcs = T.slab_pieces(lay, X, W, weights)
+    print("%-32s planes %s  (modelled gain-update cost, max/mean: %.2f)%s" % (name, show(pcs), spread(pcs), "   <- this run" if lay == LAYOUT else ""))
 del counts
 
 
@@ -135,14 +136,16 @@ class EmulatedEngine(T._DeviceCbetEngine):
         for t, peer in sends:
             out[peer] = out.get(peer, 0) + 8 * t.numel()
         with torch.cuda.stream(self.aux):
+            mine = {sf.untyped_storage().data_ptr(): k for k, sf in enumerate(self.slab_fields)}
             for t, peer in recvs:
                 inn[peer] = inn.get(peer, 0) + 8 * t.numel()
                 off = t.storage_offset()
-                if t.untyped_storage().data_ptr() == self.slab_fields.untyped_storage().data_ptr():      # a peer's beam over my slab
-                    xr = self.x1 - self.x0
-                    c, b = off // (nb * xr * plane), (off // (xr * plane)) % nb
-                    t.copy_((energy if c == 0 else fields[c])[b, self.x0:self.x1])
-                else:                                                                                     # my beam's gain over a peer's slab
+                k = mine.get(t.untyped_storage().data_ptr())
+                if k is not None:                                                                         # a peer's beam over my piece k
+                    lo, hi = self.pieces[k]
+                    c, b = off // (nb * (hi - lo) * plane), (off // ((hi - lo) * plane)) % nb
+                    t.copy_((energy if c == 0 else fields[c])[b, lo:hi])
+                else:                                                                                     # my beam's gain over a peer's piece
                     i, xs0 = off // (X * plane), (off % (X * plane)) // plane
                     t.copy_(ref_gain[self.b0 + i, xs0:xs0 + t.shape[0]])
             arrived = torch.cuda.Event()
@@ -177,13 +180,13 @@ class EmulatedEngine(T._DeviceCbetEngine):
         return out
 
 
-def run_rank(rank, link, groups, balance, passes=7):
+def run_rank(rank, link, groups, layout, passes=7):
     eng = EmulatedEngine(rank, link)
     g = type(gp).from_buffer_copy(gp)
     g.tolerance, g.max_passes = 0.0, passes
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    rep = T.cbet_fixed_point_slabs(eng, g, nb, X, rank, W, None, trace_groups=groups, balance=balance)
+    rep = T.cbet_fixed_point_slabs(eng, g, nb, X, rank, W, None, trace_groups=groups, slab_layout=layout)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     starts = [m[0] for m in eng.marks]
@@ -266,18 +269,18 @@ def model_iteration(G, t_single, t_grouped, call_ms, update_ms, host_ms=0.25, en
 rows = []
 for rank in RANKS:
     t_one, t_grp, t_single = trace_alone(rank, GROUPS)
-    run_rank(rank, LINK, GROUPS, BALANCE, passes=4)    # warm-up: allocations, streams
-    res = run_rank(rank, LINK, GROUPS, BALANCE)
+    run_rank(rank, LINK, GROUPS, LAYOUT, passes=4)     # warm-up: allocations, streams
+    res = run_rank(rank, LINK, GROUPS, LAYOUT)
     if os.environ.get("CBET_SHARE_MAIN_ONLY"):
         free = flat = res
     else:
-        free = run_rank(rank, 0.0, GROUPS, BALANCE)    # the same schedule with free links: what the exchanges still cost in it
-        flat = run_rank(rank, LINK, 1, 1.0)            # one group, slabs by plane count: nothing overlapped, the round-3 shape
+        free = run_rank(rank, 0.0, GROUPS, LAYOUT)     # the same schedule with free links: what the exchanges still cost in it
+        flat = run_rank(rank, LINK, 1, "equal")        # one group, one equal slab: nothing overlapped, the round-3 shape
     alts = {} if os.environ.get("CBET_SHARE_MAIN_ONLY") else \
-        {(gr, ba): run_rank(rank, LINK, gr, ba)["iteration"] for gr in (4, 8) for ba in (1.0, 1.15, 1.3, 2.0) if (gr, ba) != (GROUPS, BALANCE)}
-    alts[(GROUPS, BALANCE)] = res["iteration"]
+        {(gr, ba): run_rank(rank, LINK, gr, ba)["iteration"] for gr in (4, 8) for ba in ("equal", "paired", 1.15, 9.0) if (gr, ba) != (GROUPS, LAYOUT)}
+    alts[(GROUPS, LAYOUT)] = res["iteration"]
     rows.append(res)
-    print("rank %d: beams [%d,%d), slab planes [%d,%d) (%d)  -- workspace %.2f GB" % (rank, *res["beams"], *res["slab"], res["slab"][1] - res["slab"][0], res["bytes"] / 1e9))
+    print("rank %d: beams [%d,%d), planes %s  -- workspace %.2f GB" % (rank, *res["beams"], " + ".join("[%d,%d)" % pc for pc in res["slab"]), res["bytes"] / 1e9))
     print("        energy-field pass of its beams alone: %.2f ms in one launch, %.2f ms in %d groups on rotating streams; slab gain update %.2f ms"
           % (t_one, t_grp, GROUPS, res["gain"]))
     print("        steady-state iteration as issued: %.2f ms  (%.2fx of the single-GPU iteration); priced link time in it %.2f ms over %.0f grouped calls"
@@ -286,7 +289,7 @@ for rank in RANKS:
           % tuple(res["segments"][:3]))
     print("        ... host: enqueueing a pass (first trace -> update call) takes %.2f ms, update call -> next pass's first trace (exchange-2 head, scalars through the host) %.2f ms"
           % tuple(res["segments"][3:]))
-    nbr_, xr_ = res["beams"][1] - res["beams"][0], max(b_ - a_ for a_, b_ in T._parts(X, W))
+    nbr_, xr_ = res["beams"][1] - res["beams"][0], max(sum(b_ - a_ for a_, b_ in p_) for p_ in T.slab_pieces(LAYOUT, X, W, weights))
     per_beam_call = 8.0 * xr_ * plane / (LINK * 1e9) * 1e3 + CALL_US * 1e-3
     for gm in sorted({2, 4, 8, GROUPS}):
         call = per_beam_call * -(-max(q1 - q0 for q0, q1 in beams) // gm)
@@ -297,9 +300,9 @@ for rank in RANKS:
               % (gm, t_single, tg, call, res["gain"], model_iteration(gm, t_single, tg, call, res["gain"]), single / model_iteration(gm, t_single, tg, call, res["gain"])))
     print("        ... with free links: %.2f ms -> the exchanges cost %.2f ms of the iteration (their copies, calls and what the schedule cannot hide)"
           % (free["iteration"], res["iteration"] - free["iteration"]))
-    print("        ... one group, slabs by plane count (nothing overlapped): %.2f ms (%.2fx), slab gain update %.2f ms"
+    print("        ... one group, one equal slab per rank (nothing overlapped): %.2f ms (%.2fx), slab gain update %.2f ms"
           % (flat["iteration"], single / flat["iteration"], flat["gain"]))
-    print("        ... iteration [ms] by (trace groups, widest slab):", "  ".join("(%d, %.2f) %.2f" % (k[0], k[1], v) for k, v in sorted(alts.items())))
+    print("        ... iteration [ms] by (trace groups, slab layout):", "  ".join("(%d, %s) %.2f" % (k[0], k[1], v) for k, v in sorted(alts.items(), key=str)))
 worst = max(rows, key=lambda q: q["iteration"])
 print("slowest rank %d: %.2f ms -> %.2fx  (target: 1/6 of %.2f ms = %.2f ms)" % (worst["rank"], worst["iteration"], single / worst["iteration"], single, single / 6))
 dist.destroy_process_group()

@@ -22,7 +22,7 @@ gp = api.default_gain_params(relax=1.0, tolerance=1e-6, max_passes=12)
 out = {}
 for name, slabs in (("all-reduce", False), ("slabs", True)):
     e = tr.new_grid()
-    rep = tr.cbet_solve(e, gp, rank=rank, world_size=world, slabs=slabs, **(dict(balance=1.4, trace_groups=2) if (slabs and world == 3) else {}))
+    rep = tr.cbet_solve(e, gp, rank=rank, world_size=world, slabs=slabs, **(dict(slab_layout=1.4, trace_groups=2) if (slabs and world == 3) else (dict(slab_layout="paired") if slabs else {})))
     allreduce_grid(e)
     out[name] = (e.cpu().numpy(), rep)
 if rank == 0:
