@@ -71,6 +71,9 @@ static int validate(const cbet_params *p)
         return fail(CBET_EINVAL, "shard_index outside [0, shard_count)");
     if (p->rim_merge != 0 && (p->rim_merge < 2 || p->rim_merge > 16))
         return fail(CBET_EINVAL, "rim_merge must be 0 (off) or a footprint of 2 .. 16 launch zones");
+    if (p->edep_zpitch != 0 && (p->edep_zpitch < p->nz + 2 || (long)(p->ny + 2) * p->edep_zpitch >= (1L << 23) ||
+                                (long)(p->nx + 2) * (p->ny + 2) * p->edep_zpitch >= 0x7FFFFFFFL))
+        return fail(CBET_EINVAL, "edep_zpitch must be 0 (dense rows) or a row length >= nz + 2 that keeps the grid below 2^31 entries");
     return CBET_OK;
 }
 
@@ -706,6 +709,10 @@ static int trace_impl(int b, unsigned nindices, const double *ne3d, const double
     a.kap3d = kappa3d ? kappa3d : ctx->kap3d;
     a.beam_norm = beam_norm; a.bbeam_norm = bbeam_norm; a.pow_r = pow_r; a.phase_r = phase_r;
     a.edep = edep;
+    a.sYh = p->edep_zpitch > 0 ? p->edep_zpitch : p->nz + 2;
+    a.sXh = (p->ny + 2) * a.sYh;
+    if (p->edep_zpitch > 0 && (p->per_beam_grids || cbet_hooks))
+        return fail(CBET_EINVAL, "edep_zpitch applies to the plain path's single deposit grid (no per-beam grids, no CBET hooks)");
     a.grid_stride = (p->per_beam_grids || hooks.quantity != 0) ? d.edep_size : 0;  // field passes are always beam-resolved
     // beam-resolved arrays may hold only the grids of beams [grid_beam0, grid_beam0 + grid_beams)
     const int gb_n = p->grid_beams > 0 ? p->grid_beams : p->nbeams, gb_0 = p->grid_beams > 0 ? p->grid_beam0 : 0;

@@ -81,6 +81,7 @@ struct TraceArgs {
     const StepRecord *steprec;              // LDS_WINDOW kernel: per-node step records built from the two tables
     const double *beam_norm, *bbeam_norm, *pow_r, *phase_r;
     double *edep;
+    int sYh, sXh;                           // strides of the haloed deposit grid in doubles: a row (nz+2, or cbet_params.edep_zpitch), a plane
     long grid_stride;                       // 0: one grid for all beams; else doubles between per-beam grids
     unsigned long long *counters;
     // bounds-audit builds (-DCBET_DEBUG_BOUNDS) only; unused otherwise

@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(kWave) k_trace_simple(const TraceArgs a)
 
     const int nx = a.nx, ny = a.ny, nz = a.nz;
     const long sY = nz, sX = (long)ny * nz;                       // node-table strides (elements)
-    const int sYh = nz + 2, sXh = (ny + 2) * (nz + 2);            // haloed edep strides (:5-7)
+    const int sYh = a.sYh, sXh = a.sXh;                           // haloed edep strides (:5-7)
     int nsteps = 0, n_atomics = 0, n_evict = 0;
     unsigned wave_steps = 0;
 
@@ -386,7 +386,7 @@ hipError_t launch_trace(const TraceArgs &a0, int variant, bool force_idx64, hipS
     TraceArgs a = a0;
 #ifdef CBET_DEBUG_BOUNDS
     {   // the ranges the audited accesses are checked against
-        const long cells = (long)(a.nx + 2) * (a.ny + 2) * (a.nz + 2);
+        const long cells = (long)(a.nx + 2) * a.sXh;
         a.audit_lo = a.edep;
         a.audit_hi = a.edep + (a.grid_stride ? a.grid_stride * (long)(a.beam_lo - a.grid_beam0 + a.nbeams_local) : cells);
         if (a.quantity != 0) a.audit_hi = a.edep + 4 * a.comp_stride;   // the field pass writes four component arrays

@@ -442,7 +442,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
     if (live == 0ull) return;  // whole bundle culled (cannot happen for a listed patch; cheap guard)
 
     const int nx = a.nx, ny = a.ny, nz = a.nz;
-    const int sYh = nz + 2, sXh = (ny + 2) * (nz + 2);    // haloed edep strides (:5-7)
+    const int sYh = a.sYh, sXh = a.sXh;                   // haloed edep strides (:5-7; rows of nz+2 doubles unless the caller's grid is padded)
     unsigned cell = alive ? (unsigned)((s.ci * ny + s.cj) * nz + s.ck) : 0u;
     double fcx = (double)s.ci, fcy = (double)s.cj, fcz = (double)s.ck;   // the cell as the reference's (double)thisx
     int tot_steps = 0;              // wave-uniform: ray-steps of this bundle (popcount of `live` per step)

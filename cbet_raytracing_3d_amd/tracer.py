@@ -10,6 +10,8 @@ its private (nx+2)(ny+2)(nz+2) grid, and the grids are combined by one reduce-sc
 (rank r ends up owning slab r of the sum: SweepPipeline, reduce_scatter_grid); allreduce_grid is kept
 for callers that need the whole sum on every rank.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -239,7 +241,7 @@ class SweepPipeline:
     the serial launch -> D2H -> host sum of main.cu:166-210.  The combined result of a pass is slab r of the
     grid on rank r (reduce_scatter_grid)."""
 
-    def __init__(self, tracer, rank=0, world_size=1, group=None, overlap_traces=None, force_collectives=False):
+    def __init__(self, tracer, rank=0, world_size=1, group=None, overlap_traces=None, force_collectives=False, pad_rows=None):
         self.tr, self.rank, self.world, self.group = tracer, rank, world_size, group
         self.force = force_collectives      # run the RCCL combine on one rank too (smoke test of the collective path)
         # a rank's share of a sharded pass is a short launch whose drain is a quarter of it: overlap consecutive
@@ -249,10 +251,19 @@ class SweepPipeline:
         p = tracer.params
         self.ctx = [tracer.ctx, api.Context(p, tracer.gpu)]
         planes = -(-(p.nx + 2) // world_size) * world_size          # padded to a multiple of the world size
-        shape = (planes, p.ny + 2, p.nz + 2)
+        # The private grids are this class's own, so their rows are padded to whole 64-byte lines (cbet_params.edep_zpitch).
+        # With dense rows of nz + 2 = 258 doubles the pass time depends on where the grid happens to land relative to the
+        # record table -- 16.9 ... 18.6 ms from one allocation to the next, reproducibly per placement (the memory channel an
+        # address maps to folds address bits 7 apart: scripts/placement_sweep.py) --; with rows of 264 it does not.
+        # `slabs` are views of the padded slabs with the reference's (.., ny+2, nz+2) shape.
+        if pad_rows is None:
+            pad_rows = int(os.environ.get("CBET_PAD_ROWS", "1"))      # 0: dense rows; 1: the next multiple of 8 doubles; > nz + 2: that pitch
+        zp = int(pad_rows) if int(pad_rows) > p.nz + 2 else (-(-(p.nz + 2) // 8) * 8 if pad_rows else p.nz + 2)
+        shape = (planes, p.ny + 2, zp)
         dev = tracer.device
         self.grids = [torch.zeros(shape, dtype=torch.float64, device=dev) for _ in range(2)]
-        self.slabs = [torch.zeros((planes // world_size,) + shape[1:], dtype=torch.float64, device=dev) for _ in range(2)]
+        self.slab_store = [torch.zeros((planes // world_size,) + shape[1:], dtype=torch.float64, device=dev) for _ in range(2)]
+        self.slabs = [s[..., : p.nz + 2] for s in self.slab_store]
         # one stream pair per buffer set: pass k+1 may start tracing while pass k is still draining
         self.s_prep = [torch.cuda.Stream(device=dev) for _ in range(2)]
         self.s_trace = [torch.cuda.Stream(device=dev) for _ in range(2)]
@@ -263,7 +274,8 @@ class SweepPipeline:
         self.work = [None, None]
         self.kernel_events = []
         si, sc = shard_of_rank(rank, world_size)
-        self.launch_p = p.copy(beam_lo=0, beam_hi=p.nbeams, shard_index=si, shard_count=sc)
+        self.launch_p = p.copy(beam_lo=0, beam_hi=p.nbeams, shard_index=si, shard_count=sc,
+                               edep_zpitch=zp if pad_rows else 0)
         self.passes = 0
 
     def run_pass(self, timed=False):
@@ -291,7 +303,7 @@ class SweepPipeline:
             if timed:
                 e1.record()
                 self.kernel_events.append((e0, e1))
-            self.work[b] = reduce_scatter_grid(self.grids[b], self.slabs[b], self.group, async_op=True, force=self.force)
+            self.work[b] = reduce_scatter_grid(self.grids[b], self.slab_store[b], self.group, async_op=True, force=self.force)
             # "grid b may be cleared again": recorded AFTER the combine was enqueued -- on one rank (and with gloo) the
             # combine is a copy on this very stream, and pass k+2's grid.zero_() must not overtake it; with RCCL the
             # collective runs on the process group's stream and is waited for through its work handle
@@ -326,7 +338,7 @@ class SweepPipeline:
         not part of a pass.  No-op on one rank."""
         if self.world > 1 or self.force:
             for b in range(2):
-                w = reduce_scatter_grid(self.grids[b], self.slabs[b], self.group, async_op=True, force=self.force)
+                w = reduce_scatter_grid(self.grids[b], self.slab_store[b], self.group, async_op=True, force=self.force)
                 if w is not None:
                     w.wait()
             torch.cuda.synchronize(self.tr.device)

@@ -91,6 +91,15 @@ typedef struct cbet_params {
                                  /* is one 8x8 patch).  The same rays are traced; at 256^3 lane utilisation goes from */
                                  /* 0.907 to 0.957 (1620 -> 1552 bundles per beam).  Part of the geometry a     */
                                  /* context is created for.                                                     */
+    int edep_zpitch;             /* 0 (default): `edep` has the reference's dense layout, rows of nz+2 doubles   */
+                                 /* (launch_ray_XZ.cu:5-7).  p >= nz+2: the caller's grid has rows of p doubles  */
+                                 /* -- node (i,j,k) at (i*(ny+2) + j)*p + k; the entries k >= nz+2 of a row are   */
+                                 /* padding the launch never touches.  For callers that own their deposit grid's */
+                                 /* layout (tracer.SweepPipeline pads its private grids' rows to whole 64-byte    */
+                                 /* lines): how the rows of the grid fall on the memory channels relative to the */
+                                 /* record table's decides 10 % of the pass time with dense rows of 258 doubles  */
+                                 /* (16.9 ... 18.6 ms from one process to the next) and 2 % with rows of 264      */
+                                 /* (DESIGN.md section 4.4).  Plain path only.                                    */
 } cbet_params;
 
 /* Quantities the reference derives in def.cuh / main.cu:156-161, evaluated in the same order. */

@@ -188,6 +188,12 @@ def test_error_paths_without_a_gpu(api):
             api.derive(p.copy(**shape))
         assert ei.value.code == api.EINVAL and "anisotropic" in str(ei.value)
     api.derive(p.copy(nx=2800, ny=2900, nz=3))         # 8.1e6 < 2^23 = 8.4e6: accepted
+    # a padded row pitch of the caller's deposit grid: 0 (dense) or at least nz + 2
+    api.derive(p.copy(edep_zpitch=104))
+    for bad_pitch in (101, -8, 1 << 22):
+        with pytest.raises(api.CbetError) as ei:
+            api.derive(p.copy(edep_zpitch=bad_pitch))
+        assert ei.value.code == api.EINVAL and "edep_zpitch" in str(ei.value)
     with pytest.raises(api.CbetError) as ei:           # multi_gpu.cpp:45-48
         api.moveToAndFromGPU(np.zeros(4), np.zeros(4), 32, -1)
     assert ei.value.code == api.ENODEVICE
