@@ -53,8 +53,16 @@ class RayTracer:
         self.ctx = api.Context(self.params, self.gpu)
         self.grid_shape = (self.params.nx + 2, self.params.ny + 2, self.params.nz + 2)
 
-    def new_grid(self, per_beam=False):
-        """A zeroed deposition grid; per_beam=True: one grid per beam (cbet_params.per_beam_grids)."""
+    def new_grid(self, per_beam=False, zpitch=None):
+        """A zeroed deposition grid; per_beam=True: one grid per beam (cbet_params.per_beam_grids).  zpitch: rows of that
+        many doubles (>= nz + 2; True = the next multiple of 8: whole 64-byte lines) instead of the reference's dense
+        rows -- launch() recognises such a grid by its shape (cbet_params.edep_zpitch); [..., :nz + 2] is the reference's
+        view of it.  Plain path only."""
+        if zpitch:
+            if per_beam:
+                raise ValueError("a padded row pitch applies to the plain path's single grid")
+            zp = -(-self.grid_shape[2] // 8) * 8 if zpitch is True else int(zpitch)
+            return torch.zeros(self.grid_shape[:2] + (zp,), dtype=torch.float64, device=self.device)
         shape = ((self.params.nbeams,) + self.grid_shape) if per_beam else self.grid_shape
         return torch.zeros(shape, dtype=torch.float64, device=self.device)
 
@@ -63,11 +71,13 @@ class RayTracer:
         """Enqueue one launch_ray_XYZ on torch's current stream, accumulating into `edep`."""
         per_beam = edep.dim() == 4
         want = ((self.params.nbeams,) + self.grid_shape) if per_beam else self.grid_shape
-        if edep.dtype != torch.float64 or not edep.is_contiguous() or tuple(edep.shape) != want:
-            raise ValueError("edep must be a contiguous float64 tensor of shape %s (or nbeams x that)" % (self.grid_shape,))
+        # a single grid whose rows are longer than nz + 2 is a padded grid (new_grid(zpitch=...))
+        padded = (not per_beam) and edep.dim() == 3 and tuple(edep.shape[:2]) == want[:2] and edep.shape[2] > want[2]
+        if edep.dtype != torch.float64 or not edep.is_contiguous() or (tuple(edep.shape) != want and not padded):
+            raise ValueError("edep must be a contiguous float64 tensor of shape %s (or nbeams x that, or with padded rows)" % (self.grid_shape,))
         p = self.params.copy(per_beam_grids=1 if per_beam else 0, beam_lo=beam_lo,
                              beam_hi=self.params.nbeams if beam_hi is None else beam_hi,
-                             shard_index=shard_index, shard_count=shard_count)
+                             shard_index=shard_index, shard_count=shard_count, edep_zpitch=int(edep.shape[2]) if padded else 0)
         if kernel_variant is not None:
             p.kernel_variant = kernel_variant
         if force_wide_index is not None:
