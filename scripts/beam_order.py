@@ -23,9 +23,24 @@ while left:
     j = max(left, key=lambda k: d[chain[-1], k]); chain.append(j); left.remove(j)
 orders["nearest-neighbour chain"] = chain
 orders["random"] = list(np.random.default_rng(1).permutation(60))
+# round 4: by the axis a beam travels along (x-, then y-, then z-dominant; and the three classes dealt round robin): do the
+# record table's and the grid's rows of concurrently traced beams share memory channels more in one order than in another?
+dom = np.abs(bn).argmax(1)
+by_axis = [i for a_ in range(3) for i in range(60) if dom[i] == a_]
+orders["grouped by dominant axis"] = by_axis
+cls = [[i for i in range(60) if dom[i] == a_] for a_ in range(3)]
+mixed = []
+while any(cls):
+    for c_ in cls:
+        if c_:
+            mixed.append(c_.pop(0))
+orders["dominant axes dealt round robin"] = mixed
+orders["table order (again)"] = list(range(60))
+# (grids with padded rows: the time no longer depends on where the grid landed, DESIGN.md 4.4 Placement -- round 3's runs of
+# this script could not tell orders apart below the 0.5 ms that placement alone made)
 for name, perm in orders.items():
     tr = RayTracer(api.default_params(n), r, ne, te, beam_norm=bn[perm])
-    e = tr.new_grid()
+    e = tr.new_grid(zpitch=True)
     ts = []
     for rep in range(6):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
