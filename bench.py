@@ -197,6 +197,19 @@ def roofline(prof, steps_per_launch, kernel_s, tot, steps_total):
         # test; launch_ray_XZ.cu:268-356) at 4 issue cycles each -- the rest of `frac` is index math, window logic and selects
         "reference_arithmetic_frac": (62.0 * prof["wave_steps_per_launch"] / kernel_s / VALU_ISSUE_PEAK
                                       if "wave_steps_per_launch" in prof else None),
+        # the wave's own clock (SQ_WAVE_CYCLES and its disjoint parts, quad-cycles): what a wave-step costs the wave that
+        # runs it and where that time goes; the kernel retires wave-steps at (waves per CU) / cycles_per_wave_step per CU
+        "wave_time": ({"cycles_per_wave_step": 4.0 * prof["SQ_WAVE_CYCLES_per_launch"] / prof["wave_steps_per_launch"],
+                       "waiting_frac": prof["SQ_WAIT_ANY_per_launch"] / prof["SQ_WAVE_CYCLES_per_launch"],
+                       "issue_stalled_frac": prof["SQ_WAIT_INST_ANY_per_launch"] / prof["SQ_WAVE_CYCLES_per_launch"],
+                       "issuing_frac": prof["SQ_ACTIVE_INST_ANY_per_launch"] / prof["SQ_WAVE_CYCLES_per_launch"],
+                       "instructions_per_wave_step": {k: prof["SQ_INSTS_%s_per_launch" % k] / prof["wave_steps_per_launch"]
+                                                      for k in ("VALU", "SALU", "LDS")},
+                       "note": "every vector and every scalar instruction costs its wave one quad-cycle, an LDS instruction ~7 "
+                               "(SQ_ACTIVE_INST_* / SQ_INSTS_*): the pass runs at one wave's instruction stream divided by the "
+                               "occupancy (14 waves per CU, fixed by the 11,520 B of LDS a wave holds) -- DESIGN.md 4.4"}
+                      if all(k in prof for k in ("SQ_WAVE_CYCLES_per_launch", "SQ_WAIT_ANY_per_launch", "SQ_WAIT_INST_ANY_per_launch",
+                                                 "SQ_ACTIVE_INST_ANY_per_launch", "wave_steps_per_launch")) else None),
         "formula": "frac = SQ_INSTS_VALU / kernel_s / (1024 SIMDs x 2.4 GHz / 4); secondary.frac = TCC_EA0_ATOMIC x 64 B / "
                    "kernel_s / 1.3 TB/s; hbm_measured_frac = (2 x FETCH_SIZE + WRITE_SIZE) x 1 KiB / kernel_s / 8 TB/s (FETCH_SIZE tallies 128-B line requests at 64 B on gfx950: calibrated, profiles/r2/fetch_calibration.log)",
         "note": "bound = vector-instruction issue (PMC: VALU busy the largest share of SIMD cycles); the algorithmic "

@@ -94,6 +94,12 @@ entry = {
               "a known 1 GiB with scripts/ubench/fetch_calib.hip (profiles/r2/fetch_calibration.log: exactly half of the bytes "
               "moved in every pattern); WRITE_SIZE checks out on k_step_table in the same pass (+3 %%)." % (dst, ", ".join("%s (%s)" % (means[c][1], c) for c in need)),
 }
+# the wave's own clock (quad-cycles summed over the launch's wavefronts): how a wave-step's time splits into waiting in s_waitcnt,
+# stalled on issue and issuing -- bench.py reports it as roofline.wave_time
+for c in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA",
+          "SQ_ACTIVE_INST_LDS"):
+    if c in means:
+        entry[c + "_per_launch"] = means[c][0]
 entry["shard_count"] = 1
 entries = [entry]
 # the same counter passes for ONE rank's share of a K-rank run, profiled on one GPU (bench.py --shard-of K, the middle
