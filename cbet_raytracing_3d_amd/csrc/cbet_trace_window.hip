@@ -351,15 +351,29 @@ __device__ __forceinline__ bool box_deep_inside(const Origin &o, int nx, int ny,
 // ---------------------------------------------------------------------------------------------
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 
+// WIDE = false: the table is at most 2^32 bytes (2^27 nodes, 512^3), so a record's byte offset fits the 32-bit
+// offset register of the scalar-base addressing mode: one shift instead of 64-bit address arithmetic.
+template <bool WIDE>
 __device__ __forceinline__ void record_issue(const StepRecord *base, unsigned cell, dbl2 &kxy, dbl2 &kzk)
 {
-    const char *p = reinterpret_cast<const char *>(base) + ((unsigned long long)cell << 5);
     // (the trailing comment names the destination registers in the assembly listing: tests/test_isa_audit.py checks
     // that the wait below names the same ones, i.e. that the compiler never moved the in-flight record)
-    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16\n\t; CBET_RECORD_ISSUE %0 %1"
-                 : "=&v"(kxy), "=&v"(kzk)
-                 : "v"(p)
-                 : "memory");
+    if constexpr (WIDE) {
+        const char *p = reinterpret_cast<const char *>(base) + ((unsigned long long)cell << 5);
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16\n\t; CBET_RECORD_ISSUE %0 %1"
+                     : "=&v"(kxy), "=&v"(kzk)
+                     : "v"(p)
+                     : "memory");
+    } else {
+        const unsigned off = cell << 5;
+        // (s_nop 4: the compiler may have reloaded `base` from a spill lane with v_readlane right in front of this block,
+        // and a VALU write of an SGPR needs five wait states before a vector-memory instruction reads it -- a hazard
+        // the compiler does not track into inline assembly: the audited build faulted on exactly that)
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:16\n\t; CBET_RECORD_ISSUE %0 %1"
+                     : "=&v"(kxy), "=&v"(kzk)
+                     : "v"(off), "s"(base)
+                     : "memory");
+    }
 }
 
 // pend = vector-memory instructions issued since record_issue (exact, or an underestimate -- never more)
@@ -391,6 +405,22 @@ __device__ __forceinline__ void record_wait(dbl2 &kxy, dbl2 &kzk, int pend)
                  : "+v"(kxy), "+v"(kzk)
                  : "s"(pend)
                  : "memory", "scc");
+}
+
+// a + b + c in one instruction (the compiler, left alone, shares partial sums instead: more instructions)
+__device__ __forceinline__ int add3(int a, int b, int c)
+{
+    int r;
+    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// a * b + c on 24-bit operands (the compiler picked the quarter-rate v_mad_u64_u32 for one of the two)
+__device__ __forceinline__ int mad24(int a, int b, int c)
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -471,14 +501,15 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
     dbl2 rec_kxy, rec_kzk;                   // {kx, ky}, {kz, kappa} of the ray's node
     auto gather_record = [&]() {             // all lanes (a dead lane reads node 0); see record_issue
         unsigned c = alive ? cell : 0u;
+        asm("" : "+v"(c));   // (keeps the select a 32-bit one, in front of the address arithmetic)
 #ifdef CBET_DEBUG_BOUNDS
         if (!(c < a.audit_nodes)) { audit_fail(a); c = 0u; }
 #endif
-        record_issue(a.steprec, c, rec_kxy, rec_kzk);
+        record_issue<IDX64>(a.steprec, c, rec_kxy, rec_kzk);
         wc.pend = 0;
     };
     // CBET hooks and audited builds issue vector loads the compiler tracks itself: wait for everything there
-    auto await_record = [&]() { record_wait(rec_kxy, rec_kzk, (CBET != 0 || kAudited) ? 0 : __builtin_amdgcn_readfirstlane(wc.pend)); };
+    auto await_record = [&]() { record_wait(rec_kxy, rec_kzk, (CBET != 0 || kAudited) ? 0 : wc.pend); };
     gather_record();
     await_record();
     const double *const gk = CBET && a.gain ? a.gain + (long)(beam - a.grid_beam0) * a.hsize : nullptr;  // this beam's gain grid
@@ -509,7 +540,12 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
     int own_slot = 0, own_node = 0;          // CBET = 4: the ray's own node, in box A's component tiles / in the grid
     // The deposit of the step before (:341-348): a_c * increment to the eight nodes, a_c = (Fz * Fy) * Fx.
     auto deposit_previous = [&]() {
-        const double zy00 = Fz0 * Fy0, zy10 = Fz1 * Fy0, zy01 = Fz0 * Fy1, zy11 = Fz1 * Fy1;
+        // 14 products instead of the reference's 20: ((Fz * inc) * Fy) * Fx for ((Fz * Fy) * Fx) * inc -- three roundings
+        // either way, i.e. a deposit differs from the reference's by at most 2 ulp (the sum order of the atomics already
+        // moves a cell's total by more: SURVEY 8(c)'s metric is 1e-9).  The ray's own state (position, velocity, energy,
+        // cell: everything that decides where it goes and when it stops) keeps the reference's operations one for one.
+        const double zi0 = Fz0 * inc, zi1 = Fz1 * inc;
+        const double zy00 = zi0 * Fy0, zy10 = zi1 * Fy0, zy01 = zi0 * Fy1, zy11 = zi1 * Fy1;
         // order (x,y,z) = (0,0,0) (1,0,0) (0,0,1) (1,0,1) (0,1,0) (1,1,0) (0,1,1) (1,1,1) -- :341-348 without the flips
         double wgt[8];
         wgt[0] = zy00 * Fx0;
@@ -520,8 +556,6 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         wgt[5] = zy01 * Fx1;
         wgt[6] = zy11 * Fx0;
         wgt[7] = zy11 * Fx1;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) wgt[c] = wgt[c] * inc;   // a_c * increment
         if (inbox) {
             // slot = (x & XM) * XS + (y & YM) * YS + (z & ZM) with the masks and strides of the lane's tile
             // (byte offsets throughout: a 24-bit multiply by the byte stride instead of multiply-then-shift)
@@ -529,20 +563,20 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
                 const int x0 = __mul24(X0 & xm, xs * 8) + off * 8, x1 = __mul24(X1 & xm, xs * 8) + off * 8;
                 const int y0 = __mul24(Y0 & ym, ys * 8), y1 = __mul24(Y1 & ym, ys * 8);
                 const int z0 = (Z0 & zm) * 8, z1 = (Z1 & zm) * 8;
-                const int s00 = x0 + y0, s10 = x1 + y0, s01 = x0 + y1, s11 = x1 + y1;
                 auto add = [&](int byte, double w) {
                     if (CBET_AUDIT(a, (unsigned)byte < (unsigned)NSLOT * 8u))
                         __hip_atomic_fetch_add(static_cast<double *>(__builtin_assume_aligned(reinterpret_cast<char *>(s_val) + byte, 8)),
                                                w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 };
-                add(s00 + z0, wgt[0]);
-                add(s10 + z0, wgt[1]);
-                add(s00 + z1, wgt[2]);
-                add(s10 + z1, wgt[3]);
-                add(s01 + z0, wgt[4]);
-                add(s11 + z0, wgt[5]);
-                add(s01 + z1, wgt[6]);
-                add(s11 + z1, wgt[7]);
+                // (v_add3_u32 per node: 8 adds, where sharing the x + y sums costs 12)
+                add(add3(x0, y0, z0), wgt[0]);
+                add(add3(x1, y0, z0), wgt[1]);
+                add(add3(x0, y0, z1), wgt[2]);
+                add(add3(x1, y0, z1), wgt[3]);
+                add(add3(x0, y1, z0), wgt[4]);
+                add(add3(x1, y1, z0), wgt[5]);
+                add(add3(x0, y1, z1), wgt[6]);
+                add(add3(x1, y1, z1), wgt[7]);
             };
             if (!b_active) {   // scalar branch: everything goes to box A, compile-time masks and strides
                 add8(T::XM, T::YM, T::ZM, T::XS, T::YS, 0);
@@ -626,7 +660,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         fcx = (double)s.ci;
         fcy = (double)s.cj;
         fcz = (double)s.ck;
-        cell = (unsigned)(__mul24(__mul24(s.ci, ny) + s.cj, nz) + s.ck);
+        cell = (unsigned)mad24(mad24(s.ci, ny, s.cj), nz, s.ck);
         // :296-298 absorption coefficient at the new node and the NEXT step's kicks
         gather_record();
         // ---- the previous step's deposit, in the shadow of the gather -------------------------------------
@@ -651,19 +685,25 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         // a 1e-4-wide sliver: when they are negative on every axis of every live lane (a ballot of the three sign
         // compares: ~98 % of the wave-steps) the low corner is the own node minus one and the first-visited node
         // depends on the lane's flip bits only.
-        int lx, ly, lz;                       // the lane's low corner (haloed)
-        if (((CBET_BALLOT(!(ox < 0)) | CBET_BALLOT(!(oy < 0)) | CBET_BALLOT(!(oz < 0))) & live) == 0ull) {   // scalar branch
-            lx = s.ci;
-            ly = s.cj;
-            lz = s.ck;
+        // the lane's low corner (haloed) relative to box A's origin: what the common case tests; the corner itself is
+        // rebuilt from it where a box has to move (as a value of its own it costs three copies per step)
+        int rx, ry, rz;
+        const bool ngx = ox < 0, ngy = oy < 0, ngz = oz < 0;
+        if ((live & ~(CBET_BALLOT(ngx) & CBET_BALLOT(ngy) & CBET_BALLOT(ngz))) == 0ull) {   // scalar branch
+            rx = s.ci - oA.x;
+            ry = s.cj - oA.y;
+            rz = s.ck - oA.z;
+            asm("" : "+v"(rx), "+v"(ry), "+v"(rz));   // (or the compiler merges the two branches' subtractions back into copies + one)
             X0 = s.ci + nfx; X1 = s.ci + pfx;
             Y0 = s.cj + nfy; Y1 = s.cj + pfy;
             Z0 = s.ck + nfz; Z1 = s.ck + pfz;
         } else {
-            const bool ngx = ox < 0, ngy = oy < 0, ngz = oz < 0;
-            lx = s.ci + 1 - (ngx ? 1 : 0);
-            ly = s.cj + 1 - (ngy ? 1 : 0);
-            lz = s.ck + 1 - (ngz ? 1 : 0);
+            const int lx = s.ci + 1 - (ngx ? 1 : 0);
+            const int ly = s.cj + 1 - (ngy ? 1 : 0);
+            const int lz = s.ck + 1 - (ngz ? 1 : 0);
+            rx = lx - oA.x;
+            ry = ly - oA.y;
+            rz = lz - oA.z;
             // first-visited node: the own node (the high one iff the offset is negative) unless flipped
             const bool hx = ngx != flx, hy = ngy != fly, hz = ngz != flz;
             X0 = lx + (hx ? 1 : 0); X1 = lx + (hx ? 0 : 1);
@@ -710,23 +750,25 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         }
         // ---- windows ----------------------------------------------------------------------------------
         inbox = alive;         // the lane deposits into LDS this step ...
-        tile_off = 0;          // ... into this tile (offset in doubles)
+        // ... into the tile at tile_off (in doubles): 0 whenever box B is idle -- every path that retires B leaves it so
         {
             // Common case, decided with three compares: every live lane's eight target nodes lie inside its home box
             // -- nothing has to move.  (The boxes follow on demand: the step in which a lane leaves is the step in
             // which its box is shifted, before anything is deposited.)
             const unsigned long long memA = live & ~hbm, memB = live & hbm;
-            unsigned long long out_core = memA & ~(CBET_BALLOT((unsigned)(lx - oA.x) <= (unsigned)T::SX) &
-                                                   CBET_BALLOT((unsigned)(ly - oA.y) <= (unsigned)T::SY) &
-                                                   CBET_BALLOT((unsigned)(lz - oA.z) <= (unsigned)T::SZ));
+            unsigned long long out_core = memA & ~(CBET_BALLOT((unsigned)rx <= (unsigned)T::SX) & CBET_BALLOT((unsigned)ry <= (unsigned)T::SY) &
+                                                   CBET_BALLOT((unsigned)rz <= (unsigned)T::SZ));
             if (b_active) {   // scalar branch
+                asm volatile("");   // (a real branch: if-converted, its assignments cost the common path two selects)
                 wc.slabs_bsteps += 1u;
-                out_core |= memB & ~(CBET_BALLOT((unsigned)(lx - oB.x) <= (unsigned)TB::SX) &
-                                     CBET_BALLOT((unsigned)(ly - oB.y) <= (unsigned)TB::SY) &
-                                     CBET_BALLOT((unsigned)(lz - oB.z) <= (unsigned)TB::SZ));
+                const int abx = oA.x - oB.x, aby = oA.y - oB.y, abz = oA.z - oB.z;
+                out_core |= memB & ~(CBET_BALLOT((unsigned)(rx + abx) <= (unsigned)TB::SX) &
+                                     CBET_BALLOT((unsigned)(ry + aby) <= (unsigned)TB::SY) &
+                                     CBET_BALLOT((unsigned)(rz + abz) <= (unsigned)TB::SZ));
                 tile_off = homeB ? T::N : 0;
             }
             if (out_core != 0ull) {
+                const int lx = rx + oA.x, ly = ry + oA.y, lz = rz + oA.z;   // (before box A moves)
                 // box A follows the lanes whose home it is
                 follow_box<T, NC>(a, tileA, oA, memA, lx, ly, lz, lane, edep, sXh, sYh, wc, NSLOT, a.comp_stride);
                 const unsigned long long lost_mask =
@@ -770,6 +812,8 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
                     if (any_missed) wc.steps_miss += 1u;
                     deep = !any_missed && box_deep_inside<T>(oA, nx, ny, nz) && (!b_active || box_deep_inside<TB>(oB, nx, ny, nz));
                 }
+                // (the write-back paths keep the count in a vector register; the common path's stays scalar this way)
+                wc.pend = __builtin_amdgcn_readfirstlane(wc.pend);
             } else if (!deep) {
                 deep = box_deep_inside<T>(oA, nx, ny, nz) && (!b_active || box_deep_inside<TB>(oB, nx, ny, nz));
             }
@@ -837,9 +881,10 @@ hipError_t launch_trace_window(const TraceArgs &a, bool force_idx64, hipStream_t
     const long waves = a.item_count;
     if (waves <= 0) return hipSuccess;
     const dim3 grid((unsigned)waves), block(kWave);
-    // the step records are addressed with 64 bits always; GENERIC is needed for bookkeeping mode and, with the CBET
-    // hooks, for gain grids of >= 2^32 bytes (32-bit byte offsets otherwise)
-    const bool generic = force_idx64 || (a.gain && 8ull * (unsigned long long)a.hsize >= (1ull << 32)) || a.absorption != 1;
+    // GENERIC is needed for bookkeeping mode, for step-record tables beyond 2^32 bytes (more than 2^27 nodes) and,
+    // with the CBET hooks, for gain grids of >= 2^32 bytes (32-bit byte offsets otherwise)
+    const bool generic = force_idx64 || (a.gain && 8ull * (unsigned long long)a.hsize >= (1ull << 32)) || a.absorption != 1 ||
+                         sizeof(StepRecord) * (unsigned long long)a.nx * a.ny * a.nz > (1ull << 32);
     if (a.quantity == 1) {  // the fused four-component field pass (single z-planes: four tiles per wave must fit)
         if (generic) hipLaunchKernelGGL((k_trace_window<8, true, 4>), grid, block, 0, stream, a);
         else hipLaunchKernelGGL((k_trace_window<8, false, 4>), grid, block, 0, stream, a);

@@ -54,6 +54,11 @@ def b(v, i):
 # lane -> (x, y) inside the 8x8 patch, lane -> corner code (3 bits: x, y, z flips)
 MAPPINGS = {
     "rowmajor code=x0,x1,y0 (shipped)": (lambda l: (l & 7, l >> 3), lambda l, x, y: (b(x, 0), b(x, 1), b(y, 0))),
+    # the 16 lanes of a 16-lane group = the 16 rays of ONE launch zone (4 x 4 rays): lane bits 0-1 ray x, 2-3 ray y, 4 zone x, 5 zone y
+    "zonemajor code=x0,x1,y0": (lambda l: (((l >> 4) & 1) * 4 + (l & 3), ((l >> 5) & 1) * 4 + ((l >> 2) & 3)), lambda l, x, y: (b(x, 0), b(x, 1), b(y, 0))),
+    "zonemajor code=x0,y0,x1^y1": (lambda l: (((l >> 4) & 1) * 4 + (l & 3), ((l >> 5) & 1) * 4 + ((l >> 2) & 3)), lambda l, x, y: (b(x, 0), b(y, 0), b(x, 1) ^ b(y, 1))),
+    # half zones: a group = 2 x 4 rays of each of the two zones side by side is the shipped row-major; 4 x 2 instead:
+    "halfzone-y (group = 4 x 2 rays of two zones stacked in y)": (lambda l: (((l >> 5) & 1) * 4 + (l & 3), ((l >> 3) & 1) * 4 + ((l >> 4) & 1) * 2 + ((l >> 2) & 1)), lambda l, x, y: (b(x, 0), b(x, 1), b(y, 0))),
     "rowmajor nocode": (lambda l: (l & 7, l >> 3), lambda l, x, y: (0, 0, 0)),
     "rowmajor code=x0,y0,x1": (lambda l: (l & 7, l >> 3), lambda l, x, y: (b(x, 0), b(y, 0), b(x, 1))),
     "rowmajor code=x0,y0,x1^y1": (lambda l: (l & 7, l >> 3), lambda l, x, y: (b(x, 0), b(y, 0), b(x, 1) ^ b(y, 1))),
@@ -61,7 +66,8 @@ MAPPINGS = {
 
 # slot(X, Y, Z) -> bank (mod 16 of the slot in doubles); X, Y, Z haloed node indices
 LAYOUTS = {
-    "pad 140/17 (shipped)": lambda X, Y, Z: ((X & 7) * 140 + (Y & 7) * 17 + (Z & 15)) & 15,
+    "pad 148/18 (shipped)": lambda X, Y, Z: ((X & 7) * 148 + (Y & 7) * 18 + (Z & 15)) & 15,
+    "pad 140/17 (round 2)": lambda X, Y, Z: ((X & 7) * 140 + (Y & 7) * 17 + (Z & 15)) & 15,
     "pad 151/19": lambda X, Y, Z: ((X & 7) * 151 + (Y & 7) * 19 + (Z & 15)) & 15,
     "pad 153/19": lambda X, Y, Z: ((X & 7) * 153 + (Y & 7) * 19 + (Z & 15)) & 15,
     "pad 149/19 (x=5,y=3)": lambda X, Y, Z: ((X & 7) * 149 + (Y & 7) * 19 + (Z & 15)) & 15,
