@@ -448,6 +448,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
     using TB = Tile<4, 8, 8, false>;
     constexpr bool IDX64 = GENERIC;
     constexpr int NC = (CBET == 4) ? 4 : 1;
+    constexpr bool ACC = (CBET == 0);   // deposits summed in registers until the ray's nodes change (see `accumulate`)
     constexpr int NSLOT = T::N + TB::N;                   // box A, box B
     constexpr int NLDS = NSLOT + (NC - 1) * T::DT;        // + components 1.. of box A (field pass)
     __shared__ double s_val[NLDS];
@@ -526,19 +527,21 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
     double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;   // CBET = 4: the four field quantities a step deposits
 
     bool slow = true;                        // wave-uniform: this step runs the general (face-aware) forms
-    // A step's deposit is issued during the NEXT step, between that step's record gather and its wait (the loop is
-    // rotated: the dependent chain of a step is wait -> kick -> move -> relocate -> gather, everything else fills the
-    // gather's shadow).  What a deposit needs crosses the loop edge: the six per-axis factors, the node indices, the
-    // increment, where it goes.
-    double Fx0 = 0, Fx1 = 0, Fy0 = 0, Fy1 = 0, Fz0 = 0, Fz1 = 0;
-    int X0 = 0, X1 = 0, Y0 = 0, Y1 = 0, Z0 = 0, Z1 = 0;
+    // The loop is rotated: the dependent chain of a step is wait -> kick -> move -> relocate -> gather, everything else
+    // fills the gather's shadow.
+    double Fx0 = 0, Fx1 = 0, Fy0 = 0, Fy1 = 0, Fz0 = 0, Fz1 = 0;   // the step's six per-axis factors
+    int X0 = 0, X1 = 0, Y0 = 0, Y1 = 0, Z0 = 0, Z1 = 0;            // the nodes the lane's pending sums belong to (haloed)
     double inc = 0.0;                        // :305-311 the energy the step deposits
-    bool inbox = false;                      // per lane: the deposit goes to LDS ...
+    bool inbox = false;                      // per lane: the pending sums go to LDS ...
     int tile_off = 0;                        // ... into this tile (offset in doubles)
     bool missed = false;                     // per lane: ... or straight to HBM
-    bool any_missed = false;                 // wave-uniform: some lane does
+    bool any_missed = false;                 // wave-uniform: some lane's deposit goes straight to HBM (ACC = false)
     int own_slot = 0, own_node = 0;          // CBET = 4: the ray's own node, in box A's component tiles / in the grid
-    // The deposit of the step before (:341-348): a_c * increment to the eight nodes, a_c = (Fz * Fy) * Fx.
+    // ---- deposits, the CBET kernels (ACC = false): every step's deposit goes to LDS during the NEXT step, in the shadow of
+    // that step's record gather (:341-348: a_c * increment to the eight nodes, a_c = (Fz * Fy) * Fx).  What it needs
+    // crosses the loop edge: the six per-axis factors, the node indices, the increment, where it goes.  (Their gain
+    // hooks leave no registers for the pending sums below: with them the energy-field pass spills and takes 33 ms
+    // instead of 25.)
     auto deposit_previous = [&]() {
         // 14 products instead of the reference's 20: ((Fz * inc) * Fy) * Fx for ((Fz * Fy) * Fx) * inc -- three roundings
         // either way, i.e. a deposit differs from the reference's by at most 2 ulp (the sum order of the atomics already
@@ -622,6 +625,91 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         any_missed = false;
     };
 
+    // ---- deposits, the plain trace (ACC = true): summed in registers while the ray's eight nodes stay the same ----------
+    // The deposit of a step (:341-348: a_c * increment to the eight nodes, a_c = (Fz * Fy) * Fx) is ADDED TO THE LANE'S
+    // PENDING SUMS S[8] at the end of the step; the sums go to LDS (or, for a lane outside both boxes, to HBM) only when
+    // the ray's low corner changes, or the ray ends.  A ray keeps its eight nodes for 1.9 steps on average (256^3), so
+    // a ds_add_f64 carries 47 % of the lanes instead of all of them: the LDS pipeline -- the unit this kernel is bound
+    // by -- serves 133 instead of 188 cycles per wave-step (scripts/deposit_layouts.py).  The flush happens in the NEXT
+    // step, right after the new cell is known (in the shadow of its record gather) and BEFORE that step's window pass
+    // moves anything, i.e. while the boxes still stand where the last window pass put them for exactly these nodes.
+    double S[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // pending sums for the nodes X0..Z1
+    unsigned pcell = 0u;                     // the cell those nodes were derived from
+    int khi = 0;                             // per lane, the high word of 1.0 or 0.0: 0.0 = the sums restart with the next deposit
+    bool p_odd = true;                       // wave-uniform: the nodes came from the rare (non-negative offset) branch
+    auto accumulate = [&]() {
+        // 14 products instead of the reference's 20: ((Fz * inc) * Fy) * Fx for ((Fz * Fy) * Fx) * inc -- three roundings
+        // either way, i.e. a deposit differs from the reference's by at most 2 ulp (the sum order of the atomics already
+        // moves a cell's total by more: SURVEY 8(c)'s metric is 1e-9).  The ray's own state (position, velocity, energy,
+        // cell: everything that decides where it goes and when it stops) keeps the reference's operations one for one.
+        const double zi0 = Fz0 * inc, zi1 = Fz1 * inc;
+        const double zy00 = zi0 * Fy0, zy10 = zi1 * Fy0, zy01 = zi0 * Fy1, zy11 = zi1 * Fy1;
+        // order (x,y,z) = (0,0,0) (1,0,0) (0,0,1) (1,0,1) (0,1,0) (1,1,0) (0,1,1) (1,1,1) -- :341-348 without the flips
+        const double k = __hiloint2double(khi, 0);   // S * 1 + w and S * 0 + w are exact forms of "S + w" and "w": one fma each
+        S[0] = __builtin_fma(S[0], k, zy00 * Fx0);
+        S[1] = __builtin_fma(S[1], k, zy00 * Fx1);
+        S[2] = __builtin_fma(S[2], k, zy10 * Fx0);
+        S[3] = __builtin_fma(S[3], k, zy10 * Fx1);
+        S[4] = __builtin_fma(S[4], k, zy01 * Fx0);
+        S[5] = __builtin_fma(S[5], k, zy01 * Fx1);
+        S[6] = __builtin_fma(S[6], k, zy11 * Fx0);
+        S[7] = __builtin_fma(S[7], k, zy11 * Fx1);
+        khi = 0x3ff00000;
+        if (missed) ++wc.n_miss;              // ray-steps whose deposit is bound for HBM
+    };
+    // changed: per lane, the ray's nodes are about to change (or the ray has ended)
+    auto flush_pending = [&](bool changed) {
+        const bool fl = changed && (inbox || missed);
+        if (CBET_BALLOT(fl) != 0ull) {   // scalar branch (taken in 99 % of the wave-steps: some lane always moves on)
+            if (fl && inbox) {
+                // slot = (x & XM) * XS + (y & YM) * YS + (z & ZM) with the masks and strides of the lane's tile
+                // (byte offsets throughout: a 24-bit multiply by the byte stride instead of multiply-then-shift)
+                auto add8 = [&](int xm, int ym, int zm, int xs, int ys, int off) {
+                    const int x0 = __mul24(X0 & xm, xs * 8) + off * 8, x1 = __mul24(X1 & xm, xs * 8) + off * 8;
+                    const int y0 = __mul24(Y0 & ym, ys * 8), y1 = __mul24(Y1 & ym, ys * 8);
+                    const int z0 = (Z0 & zm) * 8, z1 = (Z1 & zm) * 8;
+                    auto add = [&](int byte, double w) {
+                        if (CBET_AUDIT(a, (unsigned)byte < (unsigned)NSLOT * 8u))
+                            __hip_atomic_fetch_add(static_cast<double *>(__builtin_assume_aligned(reinterpret_cast<char *>(s_val) + byte, 8)),
+                                                   w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    };
+                    // (v_add3_u32 per node: 8 adds, where sharing the x + y sums costs 12)
+                    add(add3(x0, y0, z0), S[0]);
+                    add(add3(x1, y0, z0), S[1]);
+                    add(add3(x0, y0, z1), S[2]);
+                    add(add3(x1, y0, z1), S[3]);
+                    add(add3(x0, y1, z0), S[4]);
+                    add(add3(x1, y1, z0), S[5]);
+                    add(add3(x0, y1, z1), S[6]);
+                    add(add3(x1, y1, z1), S[7]);
+                };
+                if (!b_active) {   // scalar branch: everything goes to box A, compile-time masks and strides
+                    add8(T::XM, T::YM, T::ZM, T::XS, T::YS, 0);
+                } else {
+                    const bool toB = tile_off != 0;
+                    add8(toB ? TB::XM : T::XM, toB ? TB::YM : T::YM, toB ? TB::ZM : T::ZM, toB ? TB::XS : T::XS,
+                         toB ? TB::YS : T::YS, tile_off);
+                }
+            }
+            // window misses: eight atomics, younger than the record gather just issued -- counted for its wait
+            const bool any_out = CBET_BALLOT(fl && missed) != 0ull;
+            wc.pend += any_out ? 8 : 0;
+            if (any_out && fl && missed) {
+                const int nX0 = __mul24(X0, sXh), nX1 = __mul24(X1, sXh), nY0 = __mul24(Y0, sYh), nY1 = __mul24(Y1, sYh);
+                global_add(a, &edep[nX0 + nY0 + Z0], S[0]);
+                global_add(a, &edep[nX1 + nY0 + Z0], S[1]);
+                global_add(a, &edep[nX0 + nY0 + Z1], S[2]);
+                global_add(a, &edep[nX1 + nY0 + Z1], S[3]);
+                global_add(a, &edep[nX0 + nY1 + Z0], S[4]);
+                global_add(a, &edep[nX1 + nY1 + Z0], S[5]);
+                global_add(a, &edep[nX0 + nY1 + Z1], S[6]);
+                global_add(a, &edep[nX1 + nY1 + Z1], S[7]);
+                wc.n_atomics += 8;
+            }
+        }
+        khi = fl ? 0 : khi;
+    };
+
     for (int tt = 0; tt < a.nt; ++tt) {                        // :207
         if (live == 0ull) break;
         wc.steps_miss += 1u << 16;
@@ -663,8 +751,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         cell = (unsigned)mad24(mad24(s.ci, ny, s.cj), nz, s.ck);
         // :296-298 absorption coefficient at the new node and the NEXT step's kicks
         gather_record();
-        // ---- the previous step's deposit, in the shadow of the gather -------------------------------------
-        deposit_previous();
+        if constexpr (!ACC) deposit_previous();   // the previous step's deposit, in the shadow of the gather
         // ---- weights (:319-339) -----------------------------------------------------------------
         // Each weight is (Fz * Fy) * Fx * inc with F = (1-d) for the ray's own node along that axis and F = d
         // for the neighbour on the `sign` side (:329-336).  The neighbour lies on the side of the offset's sign
@@ -689,7 +776,15 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         // rebuilt from it where a box has to move (as a value of its own it costs three copies per step)
         int rx, ry, rz;
         const bool ngx = ox < 0, ngy = oy < 0, ngz = oz < 0;
-        if ((live & ~(CBET_BALLOT(ngx) & CBET_BALLOT(ngy) & CBET_BALLOT(ngz))) == 0ull) {   // scalar branch
+        const bool all_negative = (live & ~(CBET_BALLOT(ngx) & CBET_BALLOT(ngy) & CBET_BALLOT(ngz))) == 0ull;
+        // the pending sums leave for the nodes they belong to before those are replaced: a lane whose cell changed (the
+        // low corner is a function of the cell while the offsets are negative), every lane around the rare branch
+        if constexpr (ACC) {
+            flush_pending(!alive || cell != pcell || !all_negative || p_odd);
+            pcell = cell;
+            p_odd = !all_negative;
+        }
+        if (all_negative) {   // scalar branch
             rx = s.ci - oA.x;
             ry = s.cj - oA.y;
             rz = s.ck - oA.z;
@@ -829,6 +924,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
             inc = s.uray;
         }
         if (CBET >= 2) inc = q0;   // field passes deposit energy x path length
+        if constexpr (ACC) accumulate();   // the step's deposit joins the lane's pending sums
         // ---- termination (:351-356) --------------------------------------------------------------------
         // The six exit planes are compared only when the wave is not deep inside the grid: a lane held by a deep
         // box is more than two cells from every face, far beyond the half cell of :352-354.  Ballots of plain
@@ -847,8 +943,9 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         __builtin_amdgcn_wave_barrier();
     }
 
-    // the last step's deposit, then whatever is still in LDS
-    deposit_previous();
+    // every lane's pending sums (or the last step's deposit), then whatever is still in LDS
+    if constexpr (ACC) flush_pending(true);
+    else deposit_previous();
     __syncthreads();
     flush_box<T, NC>(a, tileA, oA, lane, edep, sXh, sYh, wc, NSLOT, a.comp_stride);
     if (b_active) flush_box<TB, 1>(a, tileB, oB, lane, edep, sXh, sYh, wc, 0, 0);
