@@ -50,17 +50,22 @@ template <int WX_, int WY_, int WZ_, bool PAD>
 struct Tile {
     static constexpr int WX = WX_, WY = WY_, WZ = WZ_;
     static constexpr int XM = WX - 1, YM = WY - 1, ZM = WZ - 1;
-    // Padded layout (doubles): ds_add_f64 costs the CU ~8 cycles when the lanes' addresses fall on different
-    // bank pairs, +2 per lane sharing a bank, +3 per lane sharing an address (scripts/ubench/lds_atomic.hip),
-    // and a bundle's footprint is a few nodes wide per axis, so rows and planes are padded.  For the 8 x 8 x 16 box:
-    // rows of 18, planes of 148 -- with box B exactly the 11,520 B that still give 14 waves per CU (measured:
-    // 11,712 B do not, and the fourteenth wave is worth 0.9 ms).  Every (row, plane) pair was scored with the
-    // measured cost law on oracle ray paths (scripts/deposit_layouts.py --pads): (18, 148) 23.1 cycles per add
-    // against 25.8 for round 2's (17, 140), the best that fits 11,008 B; in interleaved runs 16.99 against 17.57 ms.
-    // The conflict-free (18, 149) and (19, 151 / 153) need one double / 24 - 40 doubles more and lose the wave.
-    // PAD = false: the dense layout, for the rarely used second box.
-    static constexpr int YS = PAD ? (WZ == 16 ? 18 : WZ + 1) : WZ;
-    static constexpr int XS = PAD ? (WZ == 16 ? 148 : WY * YS + 4) : WY * WZ;
+    // Layout (doubles).  One ds_add_f64 costs the CU 8.3 cycles + 2 per extra lane on the busiest bank of each 16-lane
+    // group (bank = slot mod 16; same address or not makes little difference: scripts/ubench/lds_pattern_cost.hip), and a
+    // bundle's footprint is a few nodes wide per axis: stored plainly, its nodes pile up on the banks of a few z values.
+    //   * the 8 x 8 x 16 box (ROT): DENSE rows of 16 whose z index is ROTATED by 7 x + 3 y -- slot = 128 x + 16 y +
+    //     ((z + 7 x + 3 y) & 15).  Scored with the measured cost law on oracle ray paths (scripts/deposit_layouts.py
+    //     --accumulate) it equals the best padded layouts (16.1 cycles per add; rows of 18 / planes of 148: 16.4) in
+    //     8,192 B instead of 9,472: with the 2 KB box B exactly the 10,240 B that give SIXTEEN waves per CU, the cap the
+    //     121 registers set anyway.  (Round 3 shipped the padding at 14 waves: rotation costs ~20 more address
+    //     instructions per flush, which mattered when every lane deposited every step.)
+    //   * PAD without ROT (the 8 x 8 x 8 box of the field pass): rows of WZ + 1, planes padded by 4.
+    //   * neither: dense, for the rarely used second box.
+    static constexpr bool ROT = PAD && WZ == 16;
+    static constexpr int YS = (PAD && !ROT) ? WZ + 1 : WZ;
+    static constexpr int XS = (PAD && !ROT) ? WY * YS + 4 : WY * WZ;
+    // the z index inside a row: tile coordinates in, position in the row out
+    static __device__ __forceinline__ int zr(int tx, int ty, int tz) { return ROT ? ((tz + 7 * tx + 3 * ty) & ZM) : tz; }
     static constexpr int N = WX * XS;           // doubles per tile
     // largest offset of a lane's low corner from the origin at which its two nodes still lie inside
     static constexpr int SX = WX - 2, SY = WY - 2, SZ = WZ - 2;
@@ -113,10 +118,10 @@ __device__ __forceinline__ void retire_planes(const TraceArgs &a, double *tile, 
             const int idx = e * kWave + lane, r0 = idx / T::WZ, r1 = idx & T::ZM, k = abs_in<T::ZM>(o.z, r1);
             const int q = pl * IT + e;
             if (AX == 0) {
-                slot[q] = fixed * T::XS + r0 * T::YS + r1;
+                slot[q] = fixed * T::XS + r0 * T::YS + T::zr(fixed, r0, r1);
                 node[q] = c * sXh + abs_in<T::YM>(o.y, r0) * sYh + k;
             } else {
-                slot[q] = r0 * T::XS + fixed * T::YS + r1;
+                slot[q] = r0 * T::XS + fixed * T::YS + T::zr(r0, fixed, r1);
                 node[q] = abs_in<T::XM>(o.x, r0) * sXh + c * sYh + k;
             }
             const bool ok = (!(WO * T::WZ < kWave) || idx < WO * T::WZ) && CBET_AUDIT(a, (unsigned)slot[q] < (unsigned)T::N);
@@ -149,11 +154,11 @@ __device__ __forceinline__ void retire_plane(const TraceArgs &a, double *tile, c
         int slot, node, slot_d;
         const int k = abs_in<T::ZM>(o.z, r1);
         if (AX == 0) {
-            slot = fixed * T::XS + r0 * T::YS + r1;
+            slot = fixed * T::XS + r0 * T::YS + T::zr(fixed, r0, r1);
             slot_d = T::slot_d(fixed, r0, r1);
             node = coord * sXh + abs_in<T::YM>(o.y, r0) * sYh + k;
         } else {
-            slot = r0 * T::XS + fixed * T::YS + r1;
+            slot = r0 * T::XS + fixed * T::YS + T::zr(r0, fixed, r1);
             slot_d = T::slot_d(r0, fixed, r1);
             node = abs_in<T::XM>(o.x, r0) * sXh + coord * sYh + k;
         }
@@ -188,7 +193,7 @@ __device__ __forceinline__ void retire_zplane(const TraceArgs &a, double *tile, 
 {
     static_assert(T::WX * T::WY <= kWave, "one z-plane entry per lane");
     const int r0 = lane / T::WY, r1 = lane & T::YM, fixed = coord & T::ZM;
-    const int slot = r0 * T::XS + r1 * T::YS + fixed;
+    const int slot = r0 * T::XS + r1 * T::YS + T::zr(r0, r1, fixed);
     const int node = abs_in<T::XM>(o.x, r0) * sXh + abs_in<T::YM>(o.y, r1) * sYh + coord;
     const bool ok = (!(T::WX * T::WY < kWave) || lane < T::WX * T::WY) && CBET_AUDIT(a, (unsigned)slot < (unsigned)T::N);
     const double v = ok ? tile[slot] : 0.0;
@@ -221,11 +226,11 @@ __device__ __forceinline__ void retire_zbrick(const TraceArgs &a, double *tile, 
 {
     static_assert(T::WY == 8 && T::WZ == 16, "a brick is 8 rows of 8 planes per tile x index");
     const int ty = lane >> 3, kz = lane & 7;
-    const int base_slot = ty * T::YS + ((zb + kz) & T::ZM);
+    const int tz = (zb + kz) & T::ZM;
     const int base_node = abs_in<T::YM>(o.y, ty) * sYh + zb + kz;
 #pragma unroll
     for (int tx = 0; tx < T::WX; ++tx) {
-        const int slot = tx * T::XS + base_slot;
+        const int slot = tx * T::XS + ty * T::YS + T::zr(tx, ty, tz);
         if (!CBET_AUDIT(a, (unsigned)slot < (unsigned)T::N)) continue;
         const double v = tile[slot];
         wc.pend += (CBET_BALLOT(v != 0.0) != 0ull) ? 1 : 0;
@@ -537,6 +542,39 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
     bool missed = false;                     // per lane: ... or straight to HBM
     bool any_missed = false;                 // wave-uniform: some lane's deposit goes straight to HBM (ACC = false)
     int own_slot = 0, own_node = 0;          // CBET = 4: the ray's own node, in box A's component tiles / in the grid
+    // Eight sums to the lane's eight nodes X0..Z1 in LDS.  slot = (x & XM) * XS + (y & YM) * YS + zr with the masks and
+    // strides of the lane's tile (byte offsets throughout: 24-bit multiplies by the byte strides, one three-operand
+    // add per node); zr = the z index, rotated by 7 x + 3 y in box A (Tile::zr).
+    auto lds_add8 = [&](const double *w) {
+        auto add8 = [&](int xm, int ym, int zm, int xs, int ys, int off, int rot) {
+            const int xa = X0 & xm, xb = X1 & xm, ya = Y0 & ym, yb = Y1 & ym;
+            const int x0 = __mul24(xa, xs * 8) + off * 8, x1 = __mul24(xb, xs * 8) + off * 8;
+            const int y0 = __mul24(ya, ys * 8), y1 = __mul24(yb, ys * 8);
+            const int ra = 7 * xa * rot, rb = 7 * xb * rot, sa = 3 * ya * rot, sb = 3 * yb * rot;
+            auto zb = [&](int z, int r) { return ((z + r) & zm) * 8; };
+            auto add = [&](int byte, double v) {
+                if (CBET_AUDIT(a, (unsigned)byte < (unsigned)NSLOT * 8u))
+                    __hip_atomic_fetch_add(static_cast<double *>(__builtin_assume_aligned(reinterpret_cast<char *>(s_val) + byte, 8)),
+                                           v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            };
+            add(add3(x0, y0, zb(Z0, ra + sa)), w[0]);
+            add(add3(x1, y0, zb(Z0, rb + sa)), w[1]);
+            add(add3(x0, y0, zb(Z1, ra + sa)), w[2]);
+            add(add3(x1, y0, zb(Z1, rb + sa)), w[3]);
+            add(add3(x0, y1, zb(Z0, ra + sb)), w[4]);
+            add(add3(x1, y1, zb(Z0, rb + sb)), w[5]);
+            add(add3(x0, y1, zb(Z1, ra + sb)), w[6]);
+            add(add3(x1, y1, zb(Z1, rb + sb)), w[7]);
+        };
+        if (!b_active) {   // scalar branch: everything goes to box A, compile-time masks and strides
+            add8(T::XM, T::YM, T::ZM, T::XS, T::YS, 0, T::ROT ? 1 : 0);
+        } else {
+            const bool toB = tile_off != 0;
+            add8(toB ? TB::XM : T::XM, toB ? TB::YM : T::YM, toB ? TB::ZM : T::ZM, toB ? TB::XS : T::XS,
+                 toB ? TB::YS : T::YS, tile_off, (T::ROT && !toB) ? 1 : 0);
+        }
+    };
+
     // ---- deposits, the CBET kernels (ACC = false): every step's deposit goes to LDS during the NEXT step, in the shadow of
     // that step's record gather (:341-348: a_c * increment to the eight nodes, a_c = (Fz * Fy) * Fx).  What it needs
     // crosses the loop edge: the six per-axis factors, the node indices, the increment, where it goes.  (Their gain
@@ -559,36 +597,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         wgt[5] = zy01 * Fx1;
         wgt[6] = zy11 * Fx0;
         wgt[7] = zy11 * Fx1;
-        if (inbox) {
-            // slot = (x & XM) * XS + (y & YM) * YS + (z & ZM) with the masks and strides of the lane's tile
-            // (byte offsets throughout: a 24-bit multiply by the byte stride instead of multiply-then-shift)
-            auto add8 = [&](int xm, int ym, int zm, int xs, int ys, int off) {
-                const int x0 = __mul24(X0 & xm, xs * 8) + off * 8, x1 = __mul24(X1 & xm, xs * 8) + off * 8;
-                const int y0 = __mul24(Y0 & ym, ys * 8), y1 = __mul24(Y1 & ym, ys * 8);
-                const int z0 = (Z0 & zm) * 8, z1 = (Z1 & zm) * 8;
-                auto add = [&](int byte, double w) {
-                    if (CBET_AUDIT(a, (unsigned)byte < (unsigned)NSLOT * 8u))
-                        __hip_atomic_fetch_add(static_cast<double *>(__builtin_assume_aligned(reinterpret_cast<char *>(s_val) + byte, 8)),
-                                               w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                };
-                // (v_add3_u32 per node: 8 adds, where sharing the x + y sums costs 12)
-                add(add3(x0, y0, z0), wgt[0]);
-                add(add3(x1, y0, z0), wgt[1]);
-                add(add3(x0, y0, z1), wgt[2]);
-                add(add3(x1, y0, z1), wgt[3]);
-                add(add3(x0, y1, z0), wgt[4]);
-                add(add3(x1, y1, z0), wgt[5]);
-                add(add3(x0, y1, z1), wgt[6]);
-                add(add3(x1, y1, z1), wgt[7]);
-            };
-            if (!b_active) {   // scalar branch: everything goes to box A, compile-time masks and strides
-                add8(T::XM, T::YM, T::ZM, T::XS, T::YS, 0);
-            } else {
-                const bool toB = tile_off != 0;
-                add8(toB ? TB::XM : T::XM, toB ? TB::YM : T::YM, toB ? TB::ZM : T::ZM, toB ? TB::XS : T::XS,
-                     toB ? TB::YS : T::YS, tile_off);
-            }
-        }
+        if (inbox) lds_add8(wgt);
         // window misses: eight atomics, younger than the record gather just issued -- counted for its wait
         wc.pend += any_missed ? 8 : 0;
         if (any_missed && missed) {
@@ -661,36 +670,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
     auto flush_pending = [&](bool changed) {
         const bool fl = changed && (inbox || missed);
         if (CBET_BALLOT(fl) != 0ull) {   // scalar branch (taken in 99 % of the wave-steps: some lane always moves on)
-            if (fl && inbox) {
-                // slot = (x & XM) * XS + (y & YM) * YS + (z & ZM) with the masks and strides of the lane's tile
-                // (byte offsets throughout: a 24-bit multiply by the byte stride instead of multiply-then-shift)
-                auto add8 = [&](int xm, int ym, int zm, int xs, int ys, int off) {
-                    const int x0 = __mul24(X0 & xm, xs * 8) + off * 8, x1 = __mul24(X1 & xm, xs * 8) + off * 8;
-                    const int y0 = __mul24(Y0 & ym, ys * 8), y1 = __mul24(Y1 & ym, ys * 8);
-                    const int z0 = (Z0 & zm) * 8, z1 = (Z1 & zm) * 8;
-                    auto add = [&](int byte, double w) {
-                        if (CBET_AUDIT(a, (unsigned)byte < (unsigned)NSLOT * 8u))
-                            __hip_atomic_fetch_add(static_cast<double *>(__builtin_assume_aligned(reinterpret_cast<char *>(s_val) + byte, 8)),
-                                                   w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    };
-                    // (v_add3_u32 per node: 8 adds, where sharing the x + y sums costs 12)
-                    add(add3(x0, y0, z0), S[0]);
-                    add(add3(x1, y0, z0), S[1]);
-                    add(add3(x0, y0, z1), S[2]);
-                    add(add3(x1, y0, z1), S[3]);
-                    add(add3(x0, y1, z0), S[4]);
-                    add(add3(x1, y1, z0), S[5]);
-                    add(add3(x0, y1, z1), S[6]);
-                    add(add3(x1, y1, z1), S[7]);
-                };
-                if (!b_active) {   // scalar branch: everything goes to box A, compile-time masks and strides
-                    add8(T::XM, T::YM, T::ZM, T::XS, T::YS, 0);
-                } else {
-                    const bool toB = tile_off != 0;
-                    add8(toB ? TB::XM : T::XM, toB ? TB::YM : T::YM, toB ? TB::ZM : T::ZM, toB ? TB::XS : T::XS,
-                         toB ? TB::YS : T::YS, tile_off);
-                }
-            }
+            if (fl && inbox) lds_add8(S);
             // window misses: eight atomics, younger than the record gather just issued -- counted for its wait
             const bool any_out = CBET_BALLOT(fl && missed) != 0ull;
             wc.pend += any_out ? 8 : 0;

@@ -4,7 +4,10 @@ mappings, under the bank model measured with scripts/ubench/lds_pattern_cost.hip
     one ds_add_f64 = 8.3 + CB x sum over the four 16-lane groups of (lanes on the group's busiest bank - 1),
     bank = (slot in doubles) mod 16     (same address or not makes little difference: 3.0 vs 2.8 in the micro-benchmark)
 
-usage: python scripts/deposit_layouts.py [--bundles 10]
+usage: python scripts/deposit_layouts.py [--bundles 10] [--pads 137/17,148/18] [--accumulate]
+
+--accumulate scores the shipped kernel's regime instead: a lane's deposits are summed in registers while its eight nodes stay
+the same and one ds_add_f64 carries only the lanes whose nodes just changed (the sums of the nodes they leave).
 """
 import argparse
 import os
@@ -22,6 +25,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=256)
 ap.add_argument("--bundles", type=int, default=10)
 ap.add_argument("--pads", default="", help="extra padded layouts to score: XS/YS pairs, e.g. 141/17,143/18")
+ap.add_argument("--accumulate", action="store_true", help="deposits summed in registers until the ray's nodes change")
 args = ap.parse_args()
 CB = 2.0
 bn, r, ne, te = load_inputs()
@@ -76,6 +80,10 @@ LAYOUTS = {
     "dense add f=3x+7y (rotate z)": lambda X, Y, Z: (((Z & 15) + 7 * (X & 7) + 3 * (Y & 7)) & 15),
     "dense add f=5x+3y": lambda X, Y, Z: (((Z & 15) + 5 * (X & 7) + 3 * (Y & 7)) & 15),
     "dense add f=4x+2y": lambda X, Y, Z: (((Z & 15) + 4 * (X & 7) + 2 * (Y & 7)) & 15),
+    "dense add f=8x+4y": lambda X, Y, Z: (((Z & 15) + 8 * (X & 7) + 4 * (Y & 7)) & 15),
+    "dense add f=2x+4y": lambda X, Y, Z: (((Z & 15) + 2 * (X & 7) + 4 * (Y & 7)) & 15),
+    "dense add f=4x+6y": lambda X, Y, Z: (((Z & 15) + 4 * (X & 7) + 6 * (Y & 7)) & 15),
+    "dense add f=6x+2y": lambda X, Y, Z: (((Z & 15) + 6 * (X & 7) + 2 * (Y & 7)) & 15),
     "dense (no swizzle)": lambda X, Y, Z: (Z & 15),
     "ideal (all distinct banks)": None,
 }
@@ -94,13 +102,22 @@ def bundle_instructions(beam, bx, by, xy, code):
     codes = np.array([code(l, *lane_xy[l]) for l in range(64)])
     paths = [ray_path(beam, bx + x, by + y) for x, y in lane_xy]
     T = max(len(p) for p in paths)
-    for t in range(T):
+    prev, had = np.zeros((64, 3), dtype=np.int64), np.zeros(64, dtype=bool)
+    for t in range(T + (1 if args.accumulate else 0)):
         low = np.zeros((64, 3), dtype=np.int64)
         act = np.zeros(64, dtype=bool)
         for l in range(64):
             if len(paths[l]) > t:
                 low[l] = paths[l][t]
                 act[l] = True
+        if args.accumulate:   # the lanes whose nodes change (or whose ray ended) flush the sums of the nodes they leave
+            fl = had & ((low != prev).any(axis=1) | ~act)
+            cur_low, cur_had = low.copy(), act.copy()
+            low, act = prev, fl
+            prev, had = cur_low, cur_had
+            if not fl.any():
+                yield None
+                continue
         for c in range(8):
             cx, cy, cz = c & 1, (c >> 2) & 1, (c >> 1) & 1
             yield (low[:, 0] + (cx ^ codes[:, 0] ^ 1), low[:, 1] + (cy ^ codes[:, 1] ^ 1), low[:, 2] + (cz ^ codes[:, 2] ^ 1), act)
@@ -127,8 +144,12 @@ for mname, (xy, code) in MAPPINGS.items():
     tot = {k: 0.0 for k in LAYOUTS}
     n = 0
     for beam, bx, by in samples:
-        for X, Y, Z, act in bundle_instructions(beam, bx * 8, by * 8, xy, code):
+        for ins in bundle_instructions(beam, bx * 8, by * 8, xy, code):
             n += 1
+            if ins is None:       # a wave-step without a flush: eight instruction slots that cost nothing
+                n += 7
+                continue
+            X, Y, Z, act = ins
             for lname, f in LAYOUTS.items():
                 tot[lname] += 8.3 if f is None else cost(f(X, Y, Z), act)
     print(mname)

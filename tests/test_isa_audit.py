@@ -105,12 +105,15 @@ def test_native_fp64_atomics(listing):
 def test_resources_of_the_headline_instance(listing):
     (name, body), = [(n, b) for n, b in listing.items() if "ILi16ELb0ELi0E" in n]
     meta = dict(re.findall(r"\.amdhsa_(\w+)\s+(\S+)", body))
-    assert int(meta["group_segment_fixed_size"]) == 11520          # the most that still gives 14 waves per CU of 160 KB
+    assert int(meta["group_segment_fixed_size"]) == 10240          # 16 waves per CU of 160 KB
     assert int(meta["private_segment_fixed_size"]) == 0            # no scratch
     assert int(meta["next_free_vgpr"]) <= 128                      # 4 waves per SIMD
     # the step loop of the plain kernel: no fused multiply-add between the two waits' worth of code
     lines = body.splitlines()
     waits = [i for i, l in enumerate(lines) if "CBET_RECORD_WAIT" in l]
     issues = [i for i, l in enumerate(lines) if "CBET_RECORD_ISSUE" in l]
-    hot = "\n".join(lines[issues[1] - 150:waits[1] + 40])          # move / relocate / gather / deposit / weights / wait
-    assert "v_fma_f64" not in hot and "v_fmac_f64" not in hot
+    hot = lines[issues[1] - 150:waits[1] + 200]                    # move / relocate / gather / flush / weights / wait / sums
+    fused = [l.split(";")[0].split() for l in hot if "v_fma_f64" in l or "v_fmac_f64" in l]
+    # ... except the eight the source asks for by name: the pending sums, S = fma(S, k, w) with k = 1.0 or 0.0 (exact
+    # forms of S + w and w), all with the same multiplier register
+    assert len(fused) == 8 and all(f[0].startswith("v_fmac_f64") for f in fused) and len({f[-1] for f in fused}) == 1, fused
