@@ -664,7 +664,6 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         S[6] = __builtin_fma(S[6], k, zy11 * Fx0);
         S[7] = __builtin_fma(S[7], k, zy11 * Fx1);
         khi = 0x3ff00000;
-        if (missed) ++wc.n_miss;              // ray-steps whose deposit is bound for HBM
     };
     // changed: per lane, the ray's nodes are about to change (or the ray has ended)
     auto flush_pending = [&](bool changed) {
@@ -743,11 +742,26 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         // per zone the 16 lanes of rows 0-3 x columns 0-3 share a cell; bits 0 and 1 (column) and bit 3 (row)
         // give those 16 lanes all 8 orders, two lanes each.
         const double ox = (fx - fcx) - 0.5, oy = (fy - fcy) - 0.5, oz = (fz - fcz) - 0.5;   // :319-321
-        const double dm = 1.0 - fabs(ox), dn = 1.0 - fabs(oy), dl = 1.0 - fabs(oz);
-        const double ax_own = 1.0 - dm, ay_own = 1.0 - dn, az_own = 1.0 - dl;
-        Fx0 = flx ? dm : ax_own; Fx1 = flx ? ax_own : dm;
-        Fy0 = fly ? dn : ay_own; Fy1 = fly ? ay_own : dn;
-        Fz0 = flz ? dl : az_own; Fz1 = flz ? az_own : dl;
+        if constexpr (ACC) {
+            // The two factors of an axis are d = 1 - |o| and 1 - d (:329-336); which of them comes first is the lane's
+            // flip bit.  Without selects: F0 = +-(|o| - h), h = 1.0 with the sign flipped for a flipped lane (exactly
+            // d), h = 0.0 otherwise (|o| itself: the reference's 1 - (1 - |o|) up to 1.1e-16), F1 = 1 - F0 (exactly
+            // 1 - d, or exactly d).  Three instructions and one conversion per axis instead of six.
+            auto pair = [](double o, int flip, double &f0, double &f1) {
+                const double g = fabs(o) - (double)flip;
+                f0 = __hiloint2double(__double2hiint(g) ^ (flip << 31), __double2loint(g));
+                f1 = 1.0 - f0;
+            };
+            pair(ox, pfx, Fx0, Fx1);
+            pair(oy, pfy, Fy0, Fy1);
+            pair(oz, pfz, Fz0, Fz1);
+        } else {
+            const double dm = 1.0 - fabs(ox), dn = 1.0 - fabs(oy), dl = 1.0 - fabs(oz);
+            const double ax_own = 1.0 - dm, ay_own = 1.0 - dn, az_own = 1.0 - dl;
+            Fx0 = flx ? dm : ax_own; Fx1 = flx ? ax_own : dm;
+            Fy0 = fly ? dn : ay_own; Fy1 = fly ? ay_own : dn;
+            Fz0 = flz ? dl : az_own; Fz1 = flz ? az_own : dl;
+        }
         // Node indices.  The offsets are xtemp - thisx - 0.5 with |xtemp - thisx| < 0.5001, i.e. negative except in
         // a 1e-4-wide sliver: when they are negative on every axis of every live lane (a ballot of the three sign
         // compares: ~98 % of the wave-steps) the low corner is the own node minus one and the first-visited node
@@ -885,6 +899,8 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
                     tile_off = useB ? T::N : 0;
                     any_missed = CBET_BALLOT(alive && !inbox) != 0ull;
                     if (any_missed) wc.steps_miss += 1u;
+                    if (ACC && alive && !inbox) ++wc.n_miss;   // ray-steps whose deposit is bound for HBM (ACC: counted here, the
+                                                               // only place a lane can come to lie outside both boxes)
                     deep = !any_missed && box_deep_inside<T>(oA, nx, ny, nz) && (!b_active || box_deep_inside<TB>(oB, nx, ny, nz));
                 }
                 // (the write-back paths keep the count in a vector register; the common path's stays scalar this way)
