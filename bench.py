@@ -194,7 +194,8 @@ def roofline(prof, steps_per_launch, kernel_s, tot, steps_total):
                 if "SQ_LDS_IDX_ACTIVE_per_launch" in prof else None),
         # how much of the issued vector work is the reference's own arithmetic: 62 fp64 instructions per wave-step (3 kick, 6
         # drift, 6 cell units, 3 + 6 relocation, 3 conversions, 12 offsets and factors, 20 products, 2 absorption, 1 energy
-        # test; launch_ray_XZ.cu:268-356) at 4 issue cycles each -- the rest of `frac` is index math, window logic and selects
+        # test; launch_ray_XZ.cu:268-356; the kernel itself forms the deposit with 14 products + 8 fused adds into the pending
+        # sums) at 4 issue cycles each -- the rest of `frac` is index math, window logic and the flush of the sums
         "reference_arithmetic_frac": (62.0 * prof["wave_steps_per_launch"] / kernel_s / VALU_ISSUE_PEAK
                                       if "wave_steps_per_launch" in prof else None),
         # the wave's own clock (SQ_WAVE_CYCLES and its disjoint parts, quad-cycles): what a wave-step costs the wave that
@@ -205,9 +206,9 @@ def roofline(prof, steps_per_launch, kernel_s, tot, steps_total):
                        "issuing_frac": prof["SQ_ACTIVE_INST_ANY_per_launch"] / prof["SQ_WAVE_CYCLES_per_launch"],
                        "instructions_per_wave_step": {k: prof["SQ_INSTS_%s_per_launch" % k] / prof["wave_steps_per_launch"]
                                                       for k in ("VALU", "SALU", "LDS")},
-                       "note": "every vector and every scalar instruction costs its wave one quad-cycle, an LDS instruction ~7 "
-                               "(SQ_ACTIVE_INST_* / SQ_INSTS_*): the pass runs at one wave's instruction stream divided by the "
-                               "occupancy (14 waves per CU, fixed by the 11,520 B of LDS a wave holds) -- DESIGN.md 4.4"}
+                       "note": "every vector and every scalar instruction costs its wave one quad-cycle, an LDS instruction ~4-7 "
+                               "(SQ_ACTIVE_INST_* / SQ_INSTS_*); 16 waves per CU (10,240 B of LDS and 127 VGPRs a wave: both "
+                               "resources' cap), vector issue ~80 % of the SIMD cycles -- DESIGN.md 4.4"}
                       if all(k in prof for k in ("SQ_WAVE_CYCLES_per_launch", "SQ_WAIT_ANY_per_launch", "SQ_WAIT_INST_ANY_per_launch",
                                                  "SQ_ACTIVE_INST_ANY_per_launch", "wave_steps_per_launch")) else None),
         "formula": "frac = SQ_INSTS_VALU / kernel_s / (1024 SIMDs x 2.4 GHz / 4); secondary.frac = TCC_EA0_ATOMIC x 64 B / "
