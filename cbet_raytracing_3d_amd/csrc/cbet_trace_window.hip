@@ -1,13 +1,14 @@
 // cbet_trace_window.hip -- the shipped ray integrator for gfx950 (CDNA4): CBET_KERNEL_LDS_WINDOW.
 //
 // One wavefront (64 lanes, one workgroup) = one ray bundle = one 8x8-ray patch of a beam's cross
-// section.  A ray's arithmetic is the reference's, operation for operation
-// (/root/reference/launch_ray_XZ.cu:207-357; the file is built with -ffp-contract=off); what is
-// MI355X-specific is everything around it:
+// section.  Everything that decides where a ray goes and when it stops -- position, velocity, energy, cell --
+// is the reference's arithmetic, operation for operation (/root/reference/launch_ray_XZ.cu:207-357; the
+// file is built with -ffp-contract=off); the deposit is the reference's up to the last bits of its terms (14
+// products for 20, see `accumulate`).  What is MI355X-specific is everything around it:
 //
 //   * plasma: one 32-byte record per node (k_step_table: the three kicks with the reference's edge rule baked in,
 //     and the absorption coefficient), gathered once per step from inline assembly and waited for with a counted
-//     vmcnt (record_issue / record_wait); the loop is rotated so that the previous step's deposit, this step's
+//     vmcnt (record_issue / record_wait); the loop is rotated so that the flush of the pending sums, this step's
 //     weights and the window logic all run between a gather and its wait.
 //   * relocation: for cells deep inside the grid the reference's mutating-bound candidate loop
 //     (:282-292) is a function of g = f - cell alone and every difference it forms is exact, so it is
@@ -15,13 +16,16 @@
 //     literal loop on the CPU).  Whether a wave is "deep inside" is decided on the SCALAR unit from the
 //     deposit windows' origins; near the faces the wave takes the closed form with the face rules.
 //   * deposit: wave-private dense LDS tiles of fp64 accumulators ("boxes") whose origins follow the
-//     bundle.  A lane whose eight target nodes lie in its box issues eight ds_add_f64; the plane (or,
-//     along z, the 64-byte-aligned brick of 8 planes) that leaves a box when its origin moves is
-//     written back with global fp64 atomics -- z-bricks make every such atomic request a full 64-B
-//     line (the memory-side atomic path is priced per 64-B request, MI355X_MICROARCH.md "Global float
-//     atomics").  A second box adopts lanes that leave the first (bundles fan out after the turning
-//     point).  Corner order is lane-dependent so that rays sharing all 8 nodes hit different LDS
-//     addresses in any one ds_add_f64.
+//     bundle.  A lane sums its ray's deposits in eight registers while the ray's eight target nodes stay the
+//     same; when they change it issues eight ds_add_f64 into its box (plain trace; the CBET kernels
+//     deposit every step).  The plane (or, along z, the 64-byte-aligned brick of 8 planes) that leaves a
+//     box when its origin moves is written back with global fp64 atomics -- z-bricks make every such
+//     atomic request a full 64-B line (the memory-side atomic path is priced per 64-B request,
+//     MI355X_MICROARCH.md "Global float atomics").  A second box adopts lanes that leave the first
+//     (bundles fan out after the turning point).  Corner order is lane-dependent so that rays sharing all
+//     8 nodes hit different LDS addresses in any one ds_add_f64; the first box stores its rows densely
+//     with a rotated z index, which spreads a bundle's nodes over the banks in 8 KB: with the second box
+//     10,240 B per wave, 16 waves per CU.
 //
 // Template parameters: WZ = z extent of a tile (16: aligned z-bricks; 8: single z-planes, used by the
 // CBET field pass whose three extra component tiles would not fit otherwise); GENERIC = run-time
@@ -445,11 +449,11 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
 {
     using T = Tile<8, 8, WZ, true>;   // box A
     // Box B holds the few lanes that left A: 4 x 8 x 8 nodes in the dense layout, 2 KB.  Occupancy is what this
-    // latency-bound loop responds to (256^3 pass: 25.7 ms at 8 waves per CU, 21.9 at 11, 20.9 at 12, 19.3 at 14), and
-    // the LDS is what caps it: a 4 KB B (8 x 8 x 8, 12 waves) halves the window misses but costs more than it saves, and
-    // A needs its padding (dense: 40 LDS cycles per ds_add_f64, 27 ms; row pad only or plane pad only: +0.5 ms).  Shapes
-    // of the 2 KB, 256^3 pass: 8x8x4 19.26 ms (misses 1.00 % of ray-steps), 8x4x8 19.09 (0.87 %), 4x8x8 18.81 (0.86 %),
-    // 4x4x16 19.11 (1.04 %), 4x16x4 / 16x4x4 19.7 (1.18 %); placing a new B off-centre towards A changes nothing.
+    // loop responds to (256^3 pass, round 2: 25.7 ms at 8 waves per CU, 21.9 at 11, 20.9 at 12, 19.3 at 14; round 4: 16.3
+    // at 14, 15.7 at 16), and the LDS is what caps it: a 4 KB B (8 x 8 x 8) halves the window misses but costs more than
+    // it saves, and A stored plainly costs 35-40 LDS cycles per ds_add_f64 (27 ms in round 2).  Shapes of the 2 KB, 256^3
+    // pass (round 2): 8x8x4 19.26 ms (misses 1.00 % of ray-steps), 8x4x8 19.09 (0.87 %), 4x8x8 18.81 (0.86 %), 4x4x16
+    // 19.11 (1.04 %), 4x16x4 / 16x4x4 19.7 (1.18 %); placing a new B off-centre towards A changes nothing.
     using TB = Tile<4, 8, 8, false>;
     constexpr bool IDX64 = GENERIC;
     constexpr int NC = (CBET == 4) ? 4 : 1;
