@@ -424,6 +424,15 @@ __device__ __forceinline__ int add3(int a, int b, int c)
     return r;
 }
 
+// (f ^ 1) + c in one instruction: the node a lane visits first along an axis, own + 1 - flip (keeping 1 - flip in a register
+// of its own costs one, forming it every step an instruction)
+__device__ __forceinline__ int xad1(int f, int c)
+{
+    int r;
+    asm("v_xad_u32 %0, %1, 1, %2" : "=v"(r) : "v"(f), "v"(c));
+    return r;
+}
+
 // a * b + c on 24-bit operands (the compiler picked the quarter-rate v_mad_u64_u32 for one of the two)
 __device__ __forceinline__ int mad24(int a, int b, int c)
 {
@@ -544,7 +553,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
     bool inbox = false;                      // per lane: the pending sums go to LDS ...
     int tile_off = 0;                        // ... into this tile (offset in doubles)
     bool missed = false;                     // per lane: ... or straight to HBM
-    bool any_missed = false;                 // wave-uniform: some lane's deposit goes straight to HBM (ACC = false)
+    bool any_missed = false;                 // wave-uniform: the last window pass left some lane outside both boxes
     int own_slot = 0, own_node = 0;          // CBET = 4: the ray's own node, in box A's component tiles / in the grid
     // Eight sums to the lane's eight nodes X0..Z1 in LDS.  slot = (x & XM) * XS + (y & YM) * YS + zr with the masks and
     // strides of the lane's tile (byte offsets throughout: 24-bit multiplies by the byte strides, one three-operand
@@ -647,8 +656,8 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
     // step, right after the new cell is known (in the shadow of its record gather) and BEFORE that step's window pass
     // moves anything, i.e. while the boxes still stand where the last window pass put them for exactly these nodes.
     double S[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // pending sums for the nodes X0..Z1
-    unsigned pcell = 0u;                     // the cell those nodes were derived from
-    int khi = 0;                             // per lane, the high word of 1.0 or 0.0: 0.0 = the sums restart with the next deposit
+    bool restart = false;                    // per lane: the sums went out in this step's flush and restart with its deposit
+    bool moved = true;                       // per lane: this step's relocation changed the ray's cell
     bool p_odd = true;                       // wave-uniform: the nodes came from the rare (non-negative offset) branch
     auto accumulate = [&]() {
         // 14 products instead of the reference's 20: ((Fz * inc) * Fy) * Fx for ((Fz * Fy) * Fx) * inc -- three roundings
@@ -658,24 +667,27 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         const double zi0 = Fz0 * inc, zi1 = Fz1 * inc;
         const double zy00 = zi0 * Fy0, zy10 = zi1 * Fy0, zy01 = zi0 * Fy1, zy11 = zi1 * Fy1;
         // order (x,y,z) = (0,0,0) (1,0,0) (0,0,1) (1,0,1) (0,1,0) (1,1,0) (0,1,1) (1,1,1) -- :341-348 without the flips
-        const double k = __hiloint2double(khi, 0);   // S * 1 + w and S * 0 + w are exact forms of "S + w" and "w": one fma each
-        S[0] = __builtin_fma(S[0], k, zy00 * Fx0);
-        S[1] = __builtin_fma(S[1], k, zy00 * Fx1);
-        S[2] = __builtin_fma(S[2], k, zy10 * Fx0);
-        S[3] = __builtin_fma(S[3], k, zy10 * Fx1);
-        S[4] = __builtin_fma(S[4], k, zy01 * Fx0);
-        S[5] = __builtin_fma(S[5], k, zy01 * Fx1);
-        S[6] = __builtin_fma(S[6], k, zy11 * Fx0);
-        S[7] = __builtin_fma(S[7], k, zy11 * Fx1);
-        khi = 0x3ff00000;
+        // S * 1 + w and S * 0 + w are exact forms of "S + w" and "w": one fma each, written IN PLACE (left to the
+        // compiler it becomes v_fmac into the product's register and eight 64-bit copies back at the loop edge)
+        const double k = restart ? 0.0 : 1.0;
+        auto add = [&](double &sum, double w) { asm("v_fma_f64 %0, %0, %1, %2" : "+v"(sum) : "v"(k), "v"(w)); };
+        add(S[0], zy00 * Fx0);
+        add(S[1], zy00 * Fx1);
+        add(S[2], zy10 * Fx0);
+        add(S[3], zy10 * Fx1);
+        add(S[4], zy01 * Fx0);
+        add(S[5], zy01 * Fx1);
+        add(S[6], zy11 * Fx0);
+        add(S[7], zy11 * Fx1);
     };
     // changed: per lane, the ray's nodes are about to change (or the ray has ended)
     auto flush_pending = [&](bool changed) {
         const bool fl = changed && (inbox || missed);
         if (CBET_BALLOT(fl) != 0ull) {   // scalar branch (taken in 99 % of the wave-steps: some lane always moves on)
             if (fl && inbox) lds_add8(S);
-            // window misses: eight atomics, younger than the record gather just issued -- counted for its wait
-            const bool any_out = CBET_BALLOT(fl && missed) != 0ull;
+            // window misses: eight atomics, younger than the record gather just issued -- counted for its wait.  (Asked
+            // only when the last window pass left some lane outside both boxes: 1 % of the wave-steps.)
+            const bool any_out = any_missed && CBET_BALLOT(fl && missed) != 0ull;
             wc.pend += any_out ? 8 : 0;
             if (any_out && fl && missed) {
                 const int nX0 = __mul24(X0, sXh), nX1 = __mul24(X1, sXh), nY0 = __mul24(Y0, sYh), nY1 = __mul24(Y1, sYh);
@@ -690,7 +702,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
                 wc.n_atomics += 8;
             }
         }
-        khi = fl ? 0 : khi;
+        restart = fl;
     };
 
     for (int tt = 0; tt < a.nt; ++tt) {                        // :207
@@ -720,13 +732,19 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
                                      CBET_BALLOT(!(fabs(g0z) < kFarJump))) & live) != 0ull;
         // ---- relocate, gather -------------------------------------------------------------------
         if (slow) {                        // near a face (or a far jump): closed form with the candidate bounds
+            const int oi = s.ci, oj = s.cj, ok = s.ck;
             s.ci = relocate_closed(s.ci, fx, nx);
             s.cj = relocate_closed(s.cj, fy, ny);
             s.ck = relocate_closed(s.ck, fz, nz);
+            if constexpr (ACC) moved = s.ci != oi || s.cj != oj || s.ck != ok;
         } else {
             s.ci = qi;
             s.cj = qj;
             s.ck = qk;
+            // (the six compares of the three lines above, combined on the scalar unit)
+            if constexpr (ACC)
+                moved = g0x >= kNearTol || g0x < kNearTol - 1.0 || g0y >= kNearTol || g0y < kNearTol - 1.0 || g0z >= kNearTol ||
+                        g0z < kNearTol - 1.0;
         }
         fcx = (double)s.ci;
         fcy = (double)s.cj;
@@ -778,8 +796,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         // the pending sums leave for the nodes they belong to before those are replaced: a lane whose cell changed (the
         // low corner is a function of the cell while the offsets are negative), every lane around the rare branch
         if constexpr (ACC) {
-            flush_pending(!alive || cell != pcell || !all_negative || p_odd);
-            pcell = cell;
+            flush_pending(!alive || moved || !all_negative || p_odd);
             p_odd = !all_negative;
         }
         if (all_negative) {   // scalar branch
@@ -787,9 +804,9 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
             ry = s.cj - oA.y;
             rz = s.ck - oA.z;
             asm("" : "+v"(rx), "+v"(ry), "+v"(rz));   // (or the compiler merges the two branches' subtractions back into copies + one)
-            X0 = s.ci + nfx; X1 = s.ci + pfx;
-            Y0 = s.cj + nfy; Y1 = s.cj + pfy;
-            Z0 = s.ck + nfz; Z1 = s.ck + pfz;
+            X0 = xad1(pfx, s.ci); X1 = s.ci + pfx;      // (own + 1 - flip, own + flip)
+            Y0 = xad1(pfy, s.cj); Y1 = s.cj + pfy;
+            Z0 = xad1(pfz, s.ck); Z1 = s.ck + pfz;
         } else {
             const int lx = s.ci + 1 - (ngx ? 1 : 0);
             const int ly = s.cj + 1 - (ngy ? 1 : 0);
@@ -844,6 +861,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         // ---- windows ----------------------------------------------------------------------------------
         inbox = alive;         // the lane deposits into LDS this step ...
         // ... into the tile at tile_off (in doubles): 0 whenever box B is idle -- every path that retires B leaves it so
+        if constexpr (ACC) any_missed = false;   // ... and no lane lies outside both boxes, unless the window pass finds one
         {
             // Common case, decided with three compares: every live lane's eight target nodes lie inside its home box
             // -- nothing has to move.  (The boxes follow on demand: the step in which a lane leaves is the step in

@@ -116,4 +116,5 @@ def test_resources_of_the_headline_instance(listing):
     fused = [l.split(";")[0].split() for l in hot if "v_fma_f64" in l or "v_fmac_f64" in l]
     # ... except the eight the source asks for by name: the pending sums, S = fma(S, k, w) with k = 1.0 or 0.0 (exact
     # forms of S + w and w), all with the same multiplier register
-    assert len(fused) == 8 and all(f[0].startswith("v_fmac_f64") for f in fused) and len({f[-1] for f in fused}) == 1, fused
+    # (v_fma_f64 S, S, k, w: written in place from inline assembly)
+    assert len(fused) == 8 and all(f[0] == "v_fma_f64" and f[1] == f[2] for f in fused) and len({f[3] for f in fused}) == 1, fused
