@@ -183,6 +183,20 @@ __device__ __forceinline__ double gain_load(const TraceArgs &a, const double *ba
     return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + (idx * 8u));
 }
 
+// Two z-adjacent entries (idx, idx + 1) of the gain grid in ONE 16-byte gather (8-byte aligned: the hardware takes it).
+typedef double gain_pair_t __attribute__((ext_vector_type(2), aligned(8)));
+template <bool IDX64>
+__device__ __forceinline__ gain_pair_t gain_load2(const TraceArgs &a, const double *base, unsigned idx)
+{
+#ifdef CBET_DEBUG_BOUNDS
+    if (!(idx + 1u < a.audit_hsize)) { audit_fail(a); return gain_pair_t{0.0, 0.0}; }
+#else
+    (void)a;
+#endif
+    if (IDX64) return *reinterpret_cast<const gain_pair_t *>(base + idx);
+    return *reinterpret_cast<const gain_pair_t *>(reinterpret_cast<const char *>(base) + (idx * 8u));
+}
+
 // phi(x) = (exp(x) - 1) / x, |x| <= 1: degree-17 Horner polynomial of plain multiplies and adds, the
 // operation sequence the CPU checker of the CBET stage evaluates.  CBET extension only.
 __device__ __forceinline__ double phi_det(double x)

@@ -764,7 +764,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         // per zone the 16 lanes of rows 0-3 x columns 0-3 share a cell; bits 0 and 1 (column) and bit 3 (row)
         // give those 16 lanes all 8 orders, two lanes each.
         const double ox = (fx - fcx) - 0.5, oy = (fy - fcy) - 0.5, oz = (fz - fcz) - 0.5;   // :319-321
-        if constexpr (ACC) {
+        {
             // The two factors of an axis are d = 1 - |o| and 1 - d (:329-336); which of them comes first is the lane's
             // flip bit.  Without selects: F0 = +-(|o| - h), h = 1.0 with the sign flipped for a flipped lane (exactly
             // d), h = 0.0 otherwise (|o| itself: the reference's 1 - (1 - |o|) up to 1.1e-16), F1 = 1 - F0 (exactly
@@ -777,12 +777,6 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
             pair(ox, pfx, Fx0, Fx1);
             pair(oy, pfy, Fy0, Fy1);
             pair(oz, pfz, Fz0, Fz1);
-        } else {
-            const double dm = 1.0 - fabs(ox), dn = 1.0 - fabs(oy), dl = 1.0 - fabs(oz);
-            const double ax_own = 1.0 - dm, ay_own = 1.0 - dn, az_own = 1.0 - dl;
-            Fx0 = flx ? dm : ax_own; Fx1 = flx ? ax_own : dm;
-            Fy0 = fly ? dn : ay_own; Fy1 = fly ? ay_own : dn;
-            Fz0 = flz ? dl : az_own; Fz1 = flz ? az_own : dl;
         }
         // Node indices.  The offsets are xtemp - thisx - 0.5 with |xtemp - thisx| < 0.5001, i.e. negative except in
         // a 1e-4-wide sliver: when they are negative on every axis of every live lane (a ballot of the three sign
@@ -821,8 +815,6 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
             Z0 = lz + (hz ? 1 : 0); Z1 = lz + (hz ? 0 : 1);
         }
         if (CBET && alive) {   // the gain gathers are memory accesses: live lanes only
-            const double zy00 = Fz0 * Fy0, zy10 = Fz1 * Fy0, zy01 = Fz0 * Fy1, zy11 = Fz1 * Fy1;
-            const double wgt[8] = {zy00 * Fx0, zy00 * Fx1, zy10 * Fx0, zy10 * Fx1, zy01 * Fx0, zy01 * Fx1, zy11 * Fx0, zy11 * Fx1};
             // path length of the step; u_eff = the ray's energy averaged over the step
             double ds = 0.0;
             if (gk || CBET >= 2) ds = sqrt_speed(s.vx * s.vx + s.vy * s.vy + s.vz * s.vz) * a.dt;
@@ -831,13 +823,18 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
                 // K at the eight deposit nodes, weighted like the deposit.  The pairwise tree makes the
                 // sum independent of the corner order (the flips swap operands of commutative adds only).
                 const int nX0 = __mul24(X0, sXh), nX1 = __mul24(X1, sXh), nY0 = __mul24(Y0, sYh), nY1 = __mul24(Y1, sYh);
-                const double g0 = gain_load<IDX64>(a, gk, (unsigned)(nX0 + nY0 + Z0)), g1 = gain_load<IDX64>(a, gk, (unsigned)(nX1 + nY0 + Z0));
-                const double g2 = gain_load<IDX64>(a, gk, (unsigned)(nX0 + nY0 + Z1)), g3 = gain_load<IDX64>(a, gk, (unsigned)(nX1 + nY0 + Z1));
-                const double g4 = gain_load<IDX64>(a, gk, (unsigned)(nX0 + nY1 + Z0)), g5 = gain_load<IDX64>(a, gk, (unsigned)(nX1 + nY1 + Z0));
-                const double g6 = gain_load<IDX64>(a, gk, (unsigned)(nX0 + nY1 + Z1)), g7 = gain_load<IDX64>(a, gk, (unsigned)(nX1 + nY1 + Z1));
-                const double k01 = wgt[0] * g0 + wgt[1] * g1, k23 = wgt[2] * g2 + wgt[3] * g3;
-                const double k45 = wgt[4] * g4 + wgt[5] * g5, k67 = wgt[6] * g6 + wgt[7] * g7;
-                double x = ((k01 + k23) + (k45 + k67)) * ds;
+                // The two z nodes of an (x, y) column are neighbours in memory: FOUR 16-byte gathers instead of eight 8-byte
+                // ones.  The column sums take the z factors by node (lower, upper), so nothing depends on the lane's z flip;
+                // the x and y flips swap operands of commutative adds.
+                const bool z0_low = Z0 < Z1;
+                const int zl = z0_low ? Z0 : Z1;
+                const double fz_lo = z0_low ? Fz0 : Fz1, fz_hi = z0_low ? Fz1 : Fz0;
+                const gain_pair_t c00 = gain_load2<IDX64>(a, gk, (unsigned)(nX0 + nY0 + zl)), c10 = gain_load2<IDX64>(a, gk, (unsigned)(nX1 + nY0 + zl));
+                const gain_pair_t c01 = gain_load2<IDX64>(a, gk, (unsigned)(nX0 + nY1 + zl)), c11 = gain_load2<IDX64>(a, gk, (unsigned)(nX1 + nY1 + zl));
+                const double q00 = fz_lo * c00.x + fz_hi * c00.y, q10 = fz_lo * c10.x + fz_hi * c10.y;
+                const double q01 = fz_lo * c01.x + fz_hi * c01.y, q11 = fz_lo * c11.x + fz_hi * c11.y;
+                const double ksum = ((Fy0 * Fx0) * q00 + (Fy0 * Fx1) * q10) + ((Fy1 * Fx0) * q01 + (Fy1 * Fx1) * q11);
+                double x = ksum * ds;
                 if (x > a.max_exponent) x = a.max_exponent;
                 if (x < -a.max_exponent) x = -a.max_exponent;
                 // (dead lanes excluded from the vote: a.max_exponent bounds |x|, not the garbage a dead lane carries)
