@@ -724,34 +724,36 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         // :282-292 nearest-node update, deep-interior form (cbet_relocate.h relocate_deep_interior: exact for
         // kRelocateDeep <= cell <= n-3 unless the ray moved more than a cell, which sends the wave to the closed form)
         const double g0x = fx - fcx, g0y = fy - fcy, g0z = fz - fcz;
-        const int qi = s.ci + ((g0x >= kNearTol) ? 1 : 0) - ((g0x < kNearTol - 1.0) ? 1 : 0);
-        const int qj = s.cj + ((g0y >= kNearTol) ? 1 : 0) - ((g0y < kNearTol - 1.0) ? 1 : 0);
-        const int qk = s.ck + ((g0z >= kNearTol) ? 1 : 0) - ((g0z < kNearTol - 1.0) ? 1 : 0);
+        const bool upx = g0x >= kNearTol, dnx = g0x < kNearTol - 1.0, upy = g0y >= kNearTol, dny = g0y < kNearTol - 1.0,
+                   upz = g0z >= kNearTol, dnz = g0z < kNearTol - 1.0;
         // wave-uniform: this step runs the general (face-aware) forms
         slow = !deep || ((CBET_BALLOT(!(fabs(g0x) < kFarJump)) | CBET_BALLOT(!(fabs(g0y) < kFarJump)) |
                                      CBET_BALLOT(!(fabs(g0z) < kFarJump))) & live) != 0ull;
         // ---- relocate, gather -------------------------------------------------------------------
+        // The deep-interior form updates the cell IN PLACE; the rare general form takes the update back first (kept as
+        // copies for it, the old cell costs the common path three moves).
+        const int di = (upx ? 1 : 0) - (dnx ? 1 : 0), dj = (upy ? 1 : 0) - (dny ? 1 : 0), dk = (upz ? 1 : 0) - (dnz ? 1 : 0);
+        s.ci += di;
+        s.cj += dj;
+        s.ck += dk;
+        if constexpr (ACC) moved = upx || dnx || upy || dny || upz || dnz;   // (the six compares, combined on the scalar unit)
         if (slow) {                        // near a face (or a far jump): closed form with the candidate bounds
-            const int oi = s.ci, oj = s.cj, ok = s.ck;
-            s.ci = relocate_closed(s.ci, fx, nx);
-            s.cj = relocate_closed(s.cj, fy, ny);
-            s.ck = relocate_closed(s.ck, fz, nz);
+            int oi = s.ci - di, oj = s.cj - dj, ok = s.ck - dk;
+            asm volatile("" : "+v"(oi), "+v"(oj), "+v"(ok));   // (recomputed here, not carried from above the update)
+            s.ci = relocate_closed(oi, fx, nx);
+            s.cj = relocate_closed(oj, fy, ny);
+            s.ck = relocate_closed(ok, fz, nz);
             if constexpr (ACC) moved = s.ci != oi || s.cj != oj || s.ck != ok;
-        } else {
-            s.ci = qi;
-            s.cj = qj;
-            s.ck = qk;
-            // (the six compares of the three lines above, combined on the scalar unit)
-            if constexpr (ACC)
-                moved = g0x >= kNearTol || g0x < kNearTol - 1.0 || g0y >= kNearTol || g0y < kNearTol - 1.0 || g0z >= kNearTol ||
-                        g0z < kNearTol - 1.0;
         }
-        fcx = (double)s.ci;
-        fcy = (double)s.cj;
-        fcz = (double)s.ck;
         cell = (unsigned)mad24(mad24(s.ci, ny, s.cj), nz, s.ck);
         // :296-298 absorption coefficient at the new node and the NEXT step's kicks
         gather_record();
+        // (everything below reads the cell through this barrier, i.e. is scheduled BEHIND the gather's issue: left alone the
+        // compiler puts the offsets' nine instructions in front of it, on the dependent chain)
+        asm volatile("" : "+v"(s.ci), "+v"(s.cj), "+v"(s.ck));
+        fcx = (double)s.ci;
+        fcy = (double)s.cj;
+        fcz = (double)s.ck;
         if constexpr (!ACC) deposit_previous();   // the previous step's deposit, in the shadow of the gather
         // ---- weights (:319-339) -----------------------------------------------------------------
         // Each weight is (Fz * Fy) * Fx * inc with F = (1-d) for the ray's own node along that axis and F = d
