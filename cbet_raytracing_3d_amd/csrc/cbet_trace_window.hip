@@ -570,14 +570,29 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
                     __hip_atomic_fetch_add(static_cast<double *>(__builtin_assume_aligned(reinterpret_cast<char *>(s_val) + byte, 8)),
                                            v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             };
-            add(add3(x0, y0, zb(Z0, ra + sa)), w[0]);
-            add(add3(x1, y0, zb(Z0, rb + sa)), w[1]);
-            add(add3(x0, y0, zb(Z1, ra + sa)), w[2]);
-            add(add3(x1, y0, zb(Z1, rb + sa)), w[3]);
-            add(add3(x0, y1, zb(Z0, ra + sb)), w[4]);
-            add(add3(x1, y1, zb(Z0, rb + sb)), w[5]);
-            add(add3(x0, y1, zb(Z1, ra + sb)), w[6]);
-            add(add3(x1, y1, zb(Z1, rb + sb)), w[7]);
+            if constexpr (T::ROT) {
+                // both boxes are dense with power-of-two strides here: x, y and the z index are disjoint bit fields of the
+                // byte offset, so a node's offset is (z term & mask) | (x | y) -- one v_and_or_b32 behind the z sum
+                const int xy00 = x0 | y0, xy10 = x1 | y0, xy01 = x0 | y1, xy11 = x1 | y1, zm8 = zm * 8;
+                auto at = [&](int xy, int z, int r) { return (((z + r) * 8) & zm8) | xy; };
+                add(at(xy00, Z0, ra + sa), w[0]);
+                add(at(xy10, Z0, rb + sa), w[1]);
+                add(at(xy00, Z1, ra + sa), w[2]);
+                add(at(xy10, Z1, rb + sa), w[3]);
+                add(at(xy01, Z0, ra + sb), w[4]);
+                add(at(xy11, Z0, rb + sb), w[5]);
+                add(at(xy01, Z1, ra + sb), w[6]);
+                add(at(xy11, Z1, rb + sb), w[7]);
+            } else {
+                add(add3(x0, y0, zb(Z0, ra + sa)), w[0]);
+                add(add3(x1, y0, zb(Z0, rb + sa)), w[1]);
+                add(add3(x0, y0, zb(Z1, ra + sa)), w[2]);
+                add(add3(x1, y0, zb(Z1, rb + sa)), w[3]);
+                add(add3(x0, y1, zb(Z0, ra + sb)), w[4]);
+                add(add3(x1, y1, zb(Z0, rb + sb)), w[5]);
+                add(add3(x0, y1, zb(Z1, ra + sb)), w[6]);
+                add(add3(x1, y1, zb(Z1, rb + sb)), w[7]);
+            }
         };
         if (!b_active) {   // scalar branch: everything goes to box A, compile-time masks and strides
             add8(T::XM, T::YM, T::ZM, T::XS, T::YS, 0, T::ROT ? 1 : 0);
