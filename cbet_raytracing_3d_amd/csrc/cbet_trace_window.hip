@@ -433,11 +433,14 @@ __device__ __forceinline__ int xad1(int f, int c)
     return r;
 }
 
-// a * b + c on 24-bit operands (the compiler picked the quarter-rate v_mad_u64_u32 for one of the two)
+// a * b + c on 24-bit operands (the compiler picked the quarter-rate v_mad_u64_u32 for one of the two).  b is a scalar
+// register: on gfx940 / gfx950 a vector instruction that reads an SGPR needs two wait states after a vector instruction
+// that wrote it (a v_readlane reloading it from a spill lane), a hazard the compiler tracks for its own instructions
+// but not into inline assembly -- hence the s_nop.
 __device__ __forceinline__ int mad24(int a, int b, int c)
 {
     int r;
-    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    asm("s_nop 1\n\tv_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
     return r;
 }
 
