@@ -61,7 +61,7 @@ struct Tile {
     //     ((z + 7 x + 3 y) & 15).  Scored with the measured cost law on oracle ray paths (scripts/deposit_layouts.py
     //     --accumulate) it equals the best padded layouts (16.1 cycles per add; rows of 18 / planes of 148: 16.4) in
     //     8,192 B instead of 9,472: with the 2 KB box B exactly the 10,240 B that give SIXTEEN waves per CU, the cap the
-    //     121 registers set anyway.  (Round 3 shipped the padding at 14 waves: rotation costs ~20 more address
+    //     127 registers set anyway.  (Round 3 shipped the padding at 14 waves: rotation costs ~20 more address
     //     instructions per flush, which mattered when every lane deposited every step.)
     //   * PAD without ROT (the 8 x 8 x 8 box of the field pass): rows of WZ + 1, planes padded by 4.
     //   * neither: dense, for the rarely used second box.
