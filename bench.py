@@ -164,14 +164,16 @@ def roofline(prof, steps_per_launch, kernel_s, tot, steps_total):
     counts of the committed rocprofv3 --pmc passes (profiles/r*/traffic.json) -- counts, not times: they are
     fixed by the workload, the time is this run's.  frac = achieved / peak."""
     alg = steps_per_launch * BYTES_PER_RAY_STEP / kernel_s
+    dsteps = max(1.0, tot[10].item())        # ray-steps of the diagnostic launch(es) the window counts belong to
     out = {"kernel": "k_trace_window", "kernel_ms": 1e3 * kernel_s,
            "bytes_per_ray_step": BYTES_PER_RAY_STEP, "algorithmic_GBps": alg / 1e9,
-           "global_atomics_per_ray_step": tot[1].item() / max(1.0, steps_total),
-           "lane_utilisation": steps_total / max(1.0, 64.0 * tot[5].item()),
-           "window_miss_ray_step_frac": tot[4].item() / max(1.0, steps_total),
+           "global_atomics_per_ray_step": tot[1].item() / dsteps,
+           "lane_utilisation": dsteps / max(1.0, 64.0 * tot[5].item()),
+           "window_miss_ray_step_frac": tot[4].item() / dsteps,
            "window_miss_wave_step_frac": tot[6].item() / max(1.0, tot[5].item()),
            "box_b_live_wave_step_frac": tot[7].item() / max(1.0, tot[5].item()),
-           "window_moves_per_wave_step": tot[8].item() / max(1.0, tot[5].item())}
+           "window_moves_per_wave_step": tot[8].item() / max(1.0, tot[5].item()),
+           "window_counts_from": "one un-timed launch with cbet_params.window_stats = 1 (the timed launches count ray-steps and rays only)"}
     if prof is None:   # no committed counter profile for this workload / kernel: nothing to price against
         out.update({"bound": "valu_issue", "achieved": None, "peak": VALU_ISSUE_PEAK / 1e9, "unit": "G wave-instructions/s",
                     "frac": None, "traffic": None,
@@ -219,14 +221,38 @@ def roofline(prof, steps_per_launch, kernel_s, tot, steps_total):
     return out
 
 
-def spawn_ranks(ngpus):
+def visible_gpu_count():
+    """HIP devices this node offers, counted WITHOUT creating a HIP / HSA context in this process: the KFD topology in
+    sysfs (nodes with simd_count > 0 are GPUs), cut down by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set.  The
+    launcher process stays off the GPU entirely; the ranks check their own device ordinal again."""
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    n = 0
+    if os.path.isdir(root):
+        for node in os.listdir(root):
+            try:
+                props = dict(l.split()[:2] for l in open(os.path.join(root, node, "properties")) if len(l.split()) >= 2)
+                n += 1 if int(props.get("simd_count", "0")) > 0 else 0
+            except (OSError, ValueError):
+                pass
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if os.environ.get(var, "").strip():
+            n = min(n, len([x for x in os.environ[var].split(",") if x.strip()]))
+    return n
+
+
+def spawn_ranks(ngpus, rank_timeout):
     """Start `ngpus` ranks of this script under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1 at a
-    free port) and return the launcher's exit code.  Runs before anything in this process has touched the GPU."""
+    free port) and return the launcher's exit code.  This process never touches the GPU (no torch import, no HIP call)
+    and nothing is exec'd: the ranks are fresh children.  They run under a parent-side limit (`--rank-timeout` seconds,
+    well inside the driver's): on expiry the whole process group of the launcher is terminated, every rank's last
+    stderr lines are printed and the exit code is 124 -- a run that hangs in RCCL's set-up cannot die silently.  Every
+    rank's stderr goes to a file of its own (CBET_BENCH_STDERR_DIR) and is replayed, labelled, when the run ends."""
+    import signal
     import socket
     import subprocess
+    import tempfile
     if "CBET_BENCH_DEVICE" not in os.environ:     # (the rehearsal override puts every rank on one device)
-        import torch                              # device_count() does not create a HIP context
-        have = torch.cuda.device_count()
+        have = visible_gpu_count()
         if ngpus > have:
             print("bench.py: --gpus %d but this node has %d HIP device(s)" % (ngpus, have), file=sys.stderr)
             return 2
@@ -238,7 +264,70 @@ def spawn_ranks(ngpus):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
     env.setdefault("OMP_NUM_THREADS", "1")
-    return subprocess.run(cmd, env=env).returncode
+    env.setdefault("NCCL_DEBUG", "WARN")                # RCCL says why when it refuses or stalls
+    logdir = tempfile.mkdtemp(prefix="cbet_bench_ranks_")
+    env["CBET_BENCH_STDERR_DIR"] = logdir
+
+    def replay(tail=None):
+        for name in sorted(os.listdir(logdir)):
+            lines = open(os.path.join(logdir, name), errors="replace").read().splitlines()
+            for line in (lines[-tail:] if tail else lines):
+                print("[%s] %s" % (name.split(".")[0], line), file=sys.stderr)
+        sys.stderr.flush()
+
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        rc = proc.wait(timeout=rank_timeout)
+    except subprocess.TimeoutExpired:
+        print("bench.py: the %d ranks did not finish within %d s (--rank-timeout): terminating them" % (ngpus, rank_timeout),
+              file=sys.stderr)
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(proc.pid, sig)               # the launcher's own session: it and every rank, nothing else
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        replay(tail=30)
+        return 124
+    replay(tail=None if rc == 0 else 60)
+    return rc
+
+
+def dense_layout_times(api, RayTracer, SweepPipeline, p, r, ne, te, bn, samples):
+    """The same trace launch into the REFERENCE's deposit-grid layout -- dense rows of nz + 2 doubles (def.cuh:121-131,
+    main.cu:262, launch_ray_XZ.cu:5-7), what a caller of cbet_launch_ray_XYZ holding the reference's array gets -- timed on
+    `samples` fresh (context, grid) allocations kept alive side by side: with dense rows the time depends on where the grid
+    lands relative to the record table (Placement), so the spread is reported, not one number.  Outside the
+    headline's timed region."""
+    import torch
+    keep, ms = [], []
+    for _ in range(samples):
+        t = RayTracer(p, r, ne, te, beam_norm=bn)
+        pp = SweepPipeline(t, 0, 1, pad_rows=0)
+        pp.run_pass()                       # tables and records of this context
+        ms.append(1e3 * pp.time_trace_alone(reps=3))
+        keep.append((t, pp))
+    for t, pp in keep:
+        pp.close()
+        t.close()
+    torch.cuda.synchronize()
+    return {"edep_row_pitch": int(p.nz + 2), "samples": samples, "min_ms": min(ms), "mean_ms": sum(ms) / len(ms), "max_ms": max(ms),
+            "all_ms": [round(x, 3) for x in ms],
+            "note": "k_trace_window alone (HIP events, 3 launches each) into dense (n+2)^3 grids -- the reference's edep layout "
+                    "-- on fresh context + grid allocations held side by side; the headline's grids have padded rows "
+                    "(config.edep_row_pitch)"}
+
+
+def device_identity(torch, index):
+    pr = torch.cuda.get_device_properties(index)
+    uuid = getattr(pr, "uuid", None)
+    return {"ordinal": int(index), "uuid": str(uuid) if uuid is not None else None,
+            "pci": "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0)),
+            "name": pr.name}
 
 
 def main():
@@ -257,6 +346,10 @@ def main():
     ap.add_argument("--shard-of", type=int, default=0, help="profiling aid, one process: trace the middle rank's share of a "
                     "K-rank run on this GPU (no process group; the combine is a local slab copy) -- how the per-share "
                     "counter profiles of profiles/r*/traffic.json are collected")
+    ap.add_argument("--rank-timeout", type=int, default=420, help="--gpus N without a launcher: seconds the N ranks may take "
+                    "before the parent terminates them and prints their last stderr lines (exit code 124)")
+    ap.add_argument("--dense-samples", type=int, default=5, help="N = 1: fresh (context, grid) allocations the trace is timed on "
+                    "with the reference's dense edep rows (reported as dense_layout, outside the timed region); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cbet", action="store_true", help="skip the (unpinned) CBET-iteration leg reported beside the headline")
     args = ap.parse_args()
@@ -267,7 +360,13 @@ def main():
         # `python bench.py --gpus N` with no launcher: this process becomes the launcher (the counterpart of the one
         # OpenMP thread per GPU of main.cu:166-176).  It never touches the GPU -- the ranks are fresh children of
         # torch.distributed.run, no exec from a process that holds a HIP context -- and relays their output and exit code.
-        sys.exit(spawn_ranks(args.gpus))
+        sys.exit(spawn_ranks(args.gpus, args.rank_timeout))
+    if os.environ.get("CBET_BENCH_STDERR_DIR") and "RANK" in os.environ:
+        # a rank started by spawn_ranks: its stderr (Python's and the native libraries') goes to a file of its own
+        fd = os.open(os.path.join(os.environ["CBET_BENCH_STDERR_DIR"], "rank%s.stderr" % os.environ["RANK"]),
+                     os.O_WRONLY | os.O_CREAT | os.O_APPEND, 0o644)
+        os.dup2(fd, 2)
+        os.close(fd)
 
     import torch
     import torch.distributed as dist
@@ -293,6 +392,11 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
         if dist.get_world_size() != args.gpus:   # "n_gpus" below is what the process group really has
             raise SystemExit("process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
+    # who is in the group: every rank's device, gathered over the process group itself (distinct devices = real GPUs)
+    identities = [device_identity(torch, device_index)]
+    if world > 1:
+        identities = [None] * world
+        dist.all_gather_object(identities, device_identity(torch, device_index))
 
     n = args.n
     r, ne, te = api.load_s83177()
@@ -325,10 +429,14 @@ def main():
 
     cnt = pipe.counters(reset=True)
     slab = pipe.finish()
-    tot = torch.tensor([float(cnt.ray_steps), float(cnt.global_atomics), elapsed,
-                        sum(a.elapsed_time(b) for a, b in pipe.kernel_events) * 1e-3, float(cnt.lds_evictions),
-                        float(cnt.wave_steps), float(cnt.wave_steps_miss), float(cnt.wave_steps_wide),
-                        float(cnt.slabs_retired), float(slab.sum().item())],
+    slab_sum = float(slab.sum().item())
+    # the deposit windows' diagnostics: ONE more launch of this rank's share, un-timed, with cbet_params.window_stats = 1
+    # (the timed launches count ray-steps and rays only); tot[1], tot[4:9] and tot[10] are that launch's counts
+    diag = pipe.window_diagnostics()
+    tot = torch.tensor([float(cnt.ray_steps), float(diag.global_atomics), elapsed,
+                        sum(a.elapsed_time(b) for a, b in pipe.kernel_events) * 1e-3, float(diag.lds_evictions),
+                        float(diag.wave_steps), float(diag.wave_steps_miss), float(diag.wave_steps_wide),
+                        float(diag.slabs_retired), slab_sum, float(diag.ray_steps)],
                        dtype=torch.float64, device="cuda")
     tmax = tot.clone()
     if world > 1:
@@ -358,6 +466,7 @@ def main():
                        "edep_sum": edep_sum, "backend": args.backend if world > 1 else None,
                        "ray_steps_per_pass": steps_total / args.steps,
                        "rays_per_pass": 60 * int(d.nlive_rays), "kernel_variant": args.variant, "rim_merge": int(p.rim_merge),
+                       "edep_row_pitch": int(pipe.launch_p.edep_zpitch) or int(p.nz + 2),   # doubles per row of the timed grids (nz + 2 = the reference's dense rows)
                        "sharding": "contiguous 1/%d parts of the beam-major ray-bundle list, %s" % (shards, COMBINE_NOTE),
                        **({"shard_emulation": "rank %d of %d on one GPU, no process group (--shard-of): `value` is this "
                                               "share's rate, a profiling aid, not a bench line" % (shards // 2, shards)}
@@ -372,6 +481,15 @@ def main():
                                  "one collected for this share of the work (traffic.json shard_count); N = 1 keeps one "
                                  "trace stream and the two are the same measurement"},
         }
+        distinct = sorted({(d["uuid"] or d["pci"], d["ordinal"]) for d in identities})
+        out["ranks"] = {"process_group_ranks": world, "backend": (args.backend if world > 1 else None),
+                        "rccl_ranks": (dist.get_world_size() if (world > 1 and args.backend == "nccl") else (1 if world == 1 else 0)),
+                        "distinct_devices": len(distinct), "devices": identities,
+                        "rehearsal": bool("CBET_BENCH_DEVICE" in os.environ or (world > 1 and args.backend != "nccl")),
+                        "note": "devices = every rank's HIP device as that rank reports it, gathered over the process group; a "
+                                "rehearsal (ranks sharing one device, or gloo) is flagged and is not a multi-GPU measurement"}
+        if world == 1 and shards == 1 and args.dense_samples > 0:
+            out["dense_layout"] = dense_layout_times(api, RayTracer, SweepPipeline, p, r, ne, te, bn, args.dense_samples)
         if world == 1 and not args.no_cbet:
             pipe.close()
             out["cbet"] = cbet_leg(api, tr, tr.new_grid(), n)

@@ -48,6 +48,7 @@ class Params(C.Structure):
         ("per_beam_grids", C.c_int), ("patch_order", C.c_int),
         ("grid_beam0", C.c_int), ("grid_beams", C.c_int),
         ("rim_merge", C.c_int), ("edep_zpitch", C.c_int),
+        ("window_stats", C.c_int),
     ]
 
     def copy(self, **overrides):

@@ -722,6 +722,7 @@ static int trace_impl(int b, unsigned nindices, const double *ne3d, const double
     a.grid_beam0 = gb_0;
     a.comp_stride = (long)gb_n * d.edep_size;
     a.counters = ctx->counters;
+    a.stats = p->window_stats != 0;
     a.gain = hooks.gain; a.hsize = d.edep_size; a.quantity = hooks.quantity;
     a.max_exponent = hooks.max_exponent; a.beam_gain = hooks.beam_gain;
     DeviceGuard guard;

@@ -84,6 +84,7 @@ struct TraceArgs {
     int sYh, sXh;                           // strides of the haloed deposit grid in doubles: a row (nz+2, or cbet_params.edep_zpitch), a plane
     long grid_stride;                       // 0: one grid for all beams; else doubles between per-beam grids
     unsigned long long *counters;
+    int stats;                              // cbet_params.window_stats: count the window diagnostics too (LDS_WINDOW kernel)
     // bounds-audit builds (-DCBET_DEBUG_BOUNDS) only; unused otherwise
     unsigned long long *audit_count;        // violations counter
     const double *audit_lo, *audit_hi;      // the grid range a launch may add into

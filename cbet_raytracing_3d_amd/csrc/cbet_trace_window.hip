@@ -93,6 +93,9 @@ struct WaveCounters {
     unsigned steps_miss = 0;  // wave-uniform, packed: wave-steps << 16 | wave-steps with a window miss
     unsigned slabs_bsteps = 0;// wave-uniform, packed: planes / bricks retired << 16 | wave-steps with box B live
     int pend = 0;             // wave-uniform: vector-memory instructions issued since the step's record gather
+#ifdef CBET_DIAG_CLOCKS
+    unsigned long long dg_ret = 0, dg_nret = 0;   // diagnostic build: shader clocks inside the write-backs of follow_box, their number
+#endif
 };
 
 // Take the plane `coord` (absolute, inside the box) of axis AX (0: x, 1: y) out of a tile: read the sums, zero the
@@ -310,14 +313,26 @@ __device__ __forceinline__ bool follow_box(const TraceArgs &a, double *tile, Ori
     };
     const int dx = follow_plane_axis(lx - o.x, mm, T::SX);
     const int dy = follow_plane_axis(ly - o.y, mm, T::SY);
-    if (dx != 0) leave(std::integral_constant<int, 0>{}, dx, o.x, o.x + T::WX - 1);
+#ifdef CBET_DIAG_CLOCKS
+    unsigned long long dg_a, dg_b;
+    auto dg_in = [&]() { asm volatile("s_memtime %0" : "=&s"(dg_a) : : "memory"); };
+    auto dg_out = [&]() {
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(dg_b) : "s"(dg_a) : "memory");
+        wc.dg_ret += dg_b - dg_a;
+        wc.dg_nret += 1;
+    };
+#else
+    auto dg_in = []() {};
+    auto dg_out = []() {};
+#endif
+    if (dx != 0) { dg_in(); leave(std::integral_constant<int, 0>{}, dx, o.x, o.x + T::WX - 1); dg_out(); }
     o.x += dx;
-    if (dy != 0) leave(std::integral_constant<int, 1>{}, dy, o.y, o.y + T::WY - 1);
+    if (dy != 0) { dg_in(); leave(std::integral_constant<int, 1>{}, dy, o.y, o.y + T::WY - 1); dg_out(); }
     o.y += dy;
     int dz;
     if constexpr (T::BRICK) {
         dz = 8 * follow_brick_axis(lz - o.z, mm);
-        if (dz != 0) retire_zbrick<T>(a, tile, o, dz < 0 ? o.z + 8 : o.z, lane, edep, sXh, sYh, wc);
+        if (dz != 0) { dg_in(); retire_zbrick<T>(a, tile, o, dz < 0 ? o.z + 8 : o.z, lane, edep, sXh, sYh, wc); dg_out(); }
     } else {
         dz = follow_plane_axis(lz - o.z, mm, T::SZ);
         if (dz != 0)
@@ -385,15 +400,13 @@ __device__ __forceinline__ void record_issue(const StepRecord *base, unsigned ce
     }
 }
 
-// pend = vector-memory instructions issued since record_issue (exact, or an underestimate -- never more)
+// pend = vector-memory instructions issued since record_issue (exact, or an underestimate -- never more).  The common
+// case -- nothing younger in flight: 75 % of the wave-steps -- is one compare and one taken branch.
 __device__ __forceinline__ void record_wait(dbl2 &kxy, dbl2 &kzk, int pend)
 {
     asm volatile("; CBET_RECORD_WAIT %0 %1\n\t"
                  "s_cmp_eq_u32 %2, 0\n\t"
-                 "s_cbranch_scc0 .Lrw_nz_%=\n\t"
-                 "s_waitcnt vmcnt(0)\n\t"
-                 "s_branch .Lrw_end_%=\n"
-                 ".Lrw_nz_%=:\n\t"
+                 "s_cbranch_scc1 .Lrw_0_%=\n\t"
                  "s_cmp_ge_u32 %2, 8\n\t"
                  "s_cbranch_scc1 .Lrw_8_%=\n\t"
                  "s_cmp_ge_u32 %2, 4\n\t"
@@ -409,11 +422,20 @@ __device__ __forceinline__ void record_wait(dbl2 &kxy, dbl2 &kzk, int pend)
                  "s_waitcnt vmcnt(4)\n\t"
                  "s_branch .Lrw_end_%=\n"
                  ".Lrw_8_%=:\n\t"
-                 "s_waitcnt vmcnt(8)\n"
+                 "s_waitcnt vmcnt(8)\n\t"
+                 "s_branch .Lrw_end_%=\n"
+                 ".Lrw_0_%=:\n\t"
+                 "s_waitcnt vmcnt(0)\n"
                  ".Lrw_end_%=:"
                  : "+v"(kxy), "+v"(kzk)
                  : "s"(pend)
                  : "memory", "scc");
+}
+
+// ... and the plain form: wait for every vector-memory instruction in flight (steps that issued nothing behind the gather)
+__device__ __forceinline__ void record_wait_all(dbl2 &kxy, dbl2 &kzk)
+{
+    asm volatile("; CBET_RECORD_WAIT %0 %1\n\ts_waitcnt vmcnt(0)" : "+v"(kxy), "+v"(kzk) : : "memory");
 }
 
 // a + b + c in one instruction (the compiler, left alone, shares partial sums instead: more instructions)
@@ -430,6 +452,15 @@ __device__ __forceinline__ int xad1(int f, int c)
 {
     int r;
     asm("v_xad_u32 %0, %1, 1, %2" : "=v"(r) : "v"(f), "v"(c));
+    return r;
+}
+
+// max(|a|, |b|, |c|) in two instructions (fmax() adds a canonicalising v_max_f64 x, x per operand); NaNs are ignored
+__device__ __forceinline__ double max_abs3(double a, double b, double c)
+{
+    double r;
+    asm("v_max_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(r), "v"(c));
     return r;
 }
 
@@ -453,10 +484,25 @@ constexpr bool kAudited = true;
 #else
 constexpr bool kAudited = false;
 #endif
+#ifdef CBET_DIAG_CLOCKS
+constexpr bool kDiagClocks = true;
+#else
+constexpr bool kDiagClocks = false;
+#endif
 constexpr double kNearTol = 0.5001;   // launch_ray_XZ.cu:132, the nearest-node tolerance
 constexpr double kFarJump = 1.4998;   // relocate_deep_interior's validity bound on |f - cell|
 
-template <int WZ, bool GENERIC, int CBET>
+// a per-lane predicate FROM a wave-uniform 64-bit mask (no instruction: the mask is used as the condition register)
+#define CBET_LANES(mask) __builtin_amdgcn_inverse_ballot_w64(mask)
+
+// Lane predicates of the step loop are kept as 64-bit masks in scalar registers and combined there explicitly: `live`
+// (the ray is still traced), `hbm` (its home is box B), `inbox_m` / `miss_m` (where its pending deposit belongs: an LDS
+// box / straight to HBM).  A per-lane copy of a predicate costs the compiler merges under the exec mask wherever it
+// crosses a branch (three scalar instructions each); a mask costs nothing until it is used (CBET_LANES).
+//
+// STATS: the window diagnostics (wave-steps, misses, box-B steps, planes retired, global atomics) are counted only by
+// this instantiation (cbet_params.window_stats); the other counts ray-steps and rays.
+template <int WZ, bool GENERIC, int CBET, bool STATS>
 __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(const TraceArgs a)
 {
     using T = Tile<8, 8, WZ, true>;   // box A
@@ -485,25 +531,22 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
     Ray s = {};   // holes and culled rays keep zeros: their lanes run the arithmetic below on harmless values
     const int li = patch * kWave + lane;
     const int pre_raynum = li < a.nlive ? a.live[li] : -1;  // -1: hole in the 8x8 patch
-    bool alive = pre_raynum >= 0;
-    if (alive) alive = launch_ray(a, beam, pre_raynum, s);
-    const int launched = alive ? 1 : 0;
-    // Lane predicates that steer wave-uniform decisions are kept as 64-bit masks in scalar registers next to
-    // the per-lane flag: `live` = ballot(alive), `hbm` = ballot(homeB); tests on them cost no vector instruction.
-    unsigned long long live = __ballot(alive);
+    bool launched = pre_raynum >= 0;
+    if (launched) launched = launch_ray(a, beam, pre_raynum, s);
+    unsigned long long live = __ballot(launched);
     if (live == 0ull) return;  // whole bundle culled (cannot happen for a listed patch; cheap guard)
+    const int tot_rays = __popcll(live);
 
     const int nx = a.nx, ny = a.ny, nz = a.nz;
     const int sYh = a.sYh, sXh = a.sXh;                   // haloed edep strides (:5-7; rows of nz+2 doubles unless the caller's grid is padded)
-    unsigned cell = alive ? (unsigned)((s.ci * ny + s.cj) * nz + s.ck) : 0u;
+    unsigned cell = launched ? (unsigned)((s.ci * ny + s.cj) * nz + s.ck) : 0u;
     double fcx = (double)s.ci, fcy = (double)s.cj, fcz = (double)s.ck;   // the cell as the reference's (double)thisx
-    int tot_steps = 0;              // wave-uniform: ray-steps of this bundle (popcount of `live` per step)
+    int tot_steps = 0;              // wave-uniform: ray-steps of this bundle (a lane's count is added when it ends)
     WaveCounters wc;
 
     double *const tileA = s_val, *const tileB = s_val + T::N;
     Origin oA{0, 0, 0}, oB{0, 0, 0};
-    bool homeB = false;            // per lane: the lane's deposits go to box B
-    unsigned long long hbm = 0ull; // its ballot
+    unsigned long long hbm = 0ull; // lanes whose deposits go to box B
     bool b_active = false;         // wave-uniform
     {
         const int src = ((live >> 27) & 1ull) ? 27 : (__ffsll((long long)live) - 1);
@@ -516,13 +559,19 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
     }
     // wave-uniform: every live lane was held by a box after the last step and both boxes lie deep inside the grid
     bool deep = false;
+#ifdef CBET_DIAG_CLOCKS
+    // diagnostic build (never shipped): shader-clock cycles this wave spends in the record wait and in the window-shift
+    // path, reported through the counter slots (see the end of the kernel)
+    unsigned long long dg_wait = 0, dg_shift = 0, dg_nshift = 0, dg_t_start;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(dg_t_start) : : "memory");
+#endif
 
     // A step's record (cbet_device.h StepRecord: the three kicks and the absorption coefficient at the ray's node) is
     // gathered as soon as the new node is known; the absorption coefficient is used at the end of the same step,
     // the kicks by the NEXT step's move.  One aligned 32-byte gather per lane and step.
     dbl2 rec_kxy, rec_kzk;                   // {kx, ky}, {kz, kappa} of the ray's node
     auto gather_record = [&]() {             // all lanes (a dead lane reads node 0); see record_issue
-        unsigned c = alive ? cell : 0u;
+        unsigned c = CBET_LANES(live) ? cell : 0u;
         asm("" : "+v"(c));   // (keeps the select a 32-bit one, in front of the address arithmetic)
 #ifdef CBET_DEBUG_BOUNDS
         if (!(c < a.audit_nodes)) { audit_fail(a); c = 0u; }
@@ -530,8 +579,23 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         record_issue<IDX64>(a.steprec, c, rec_kxy, rec_kzk);
         wc.pend = 0;
     };
-    // CBET hooks and audited builds issue vector loads the compiler tracks itself: wait for everything there
-    auto await_record = [&]() { record_wait(rec_kxy, rec_kzk, (CBET != 0 || kAudited) ? 0 : wc.pend); };
+    // The wait, counted: the vector-memory instructions the step really issued behind the gather (the window pass's
+    // write-backs, a flush's atomics) stay in flight.  CBET hooks and audited builds issue vector loads the compiler
+    // tracks itself: they wait for everything.  ONE wait site in the loop, behind the join of the window logic: with a
+    // wait in each arm the register allocator is free to give the record different registers in the arms and to copy
+    // it -- before it has arrived -- where they meet (tests/test_isa_audit.py).
+    auto await_record = [&]() {
+#ifdef CBET_DIAG_CLOCKS
+        unsigned long long t0, t1;
+        asm volatile("s_memtime %0" : "=&s"(t0) : : "memory");
+#endif
+        if (CBET == 0 && !kAudited) record_wait(rec_kxy, rec_kzk, wc.pend);
+        else record_wait_all(rec_kxy, rec_kzk);
+#ifdef CBET_DIAG_CLOCKS
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t1) : "s"(t0) : "memory");
+        dg_wait += t1 - t0;
+#endif
+    };
     gather_record();
     await_record();
     const double *const gk = CBET && a.gain ? a.gain + (long)(beam - a.grid_beam0) * a.hsize : nullptr;  // this beam's gain grid
@@ -539,7 +603,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
 
     // lane-dependent corner order (see the weights): which of an axis's two nodes a lane visits first
     const bool flx = (lane & 1) != 0, fly = (lane & 2) != 0, flz = (lane & 8) != 0;
-    const int pfx = flx ? 1 : 0, pfy = fly ? 1 : 0, pfz = flz ? 1 : 0, nfx = 1 - pfx, nfy = 1 - pfy, nfz = 1 - pfz;
+    const int pfx = flx ? 1 : 0, pfy = fly ? 1 : 0, pfz = flz ? 1 : 0;
 
     // The per-lane arithmetic of a step runs on ALL lanes, dead ones included (their state is garbage nobody reads):
     // only memory accesses and the LDS / HBM adds are predicated.  Guarding the arithmetic with `if (alive)` costs
@@ -553,10 +617,9 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
     double Fx0 = 0, Fx1 = 0, Fy0 = 0, Fy1 = 0, Fz0 = 0, Fz1 = 0;   // the step's six per-axis factors
     int X0 = 0, X1 = 0, Y0 = 0, Y1 = 0, Z0 = 0, Z1 = 0;            // the nodes the lane's pending sums belong to (haloed)
     double inc = 0.0;                        // :305-311 the energy the step deposits
-    bool inbox = false;                      // per lane: the pending sums go to LDS ...
-    int tile_off = 0;                        // ... into this tile (offset in doubles)
-    bool missed = false;                     // per lane: ... or straight to HBM
-    bool any_missed = false;                 // wave-uniform: the last window pass left some lane outside both boxes
+    unsigned long long inbox_m = 0ull;       // lanes whose pending deposit goes to LDS ...
+    int tile_off = 0;                        // ... into this tile (offset in doubles; per lane, 0 while box B is idle)
+    unsigned long long miss_m = 0ull;        // ... lanes whose pending deposit goes straight to HBM (outside both boxes)
     int own_slot = 0, own_node = 0;          // CBET = 4: the ray's own node, in box A's component tiles / in the grid
     // Eight sums to the lane's eight nodes X0..Z1 in LDS.  slot = (x & XM) * XS + (y & YM) * YS + zr with the masks and
     // strides of the lane's tile (byte offsets throughout: 24-bit multiplies by the byte strides, one three-operand
@@ -605,6 +668,19 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
                  toB ? TB::YS : T::YS, tile_off, (T::ROT && !toB) ? 1 : 0);
         }
     };
+    // eight values to the lane's eight nodes X0..Z1 in HBM (a lane outside both boxes)
+    auto hbm_add8 = [&](const double *w) {
+        const int nX0 = __mul24(X0, sXh), nX1 = __mul24(X1, sXh), nY0 = __mul24(Y0, sYh), nY1 = __mul24(Y1, sYh);
+        global_add(a, &edep[nX0 + nY0 + Z0], w[0]);
+        global_add(a, &edep[nX1 + nY0 + Z0], w[1]);
+        global_add(a, &edep[nX0 + nY0 + Z1], w[2]);
+        global_add(a, &edep[nX1 + nY0 + Z1], w[3]);
+        global_add(a, &edep[nX0 + nY1 + Z0], w[4]);
+        global_add(a, &edep[nX1 + nY1 + Z0], w[5]);
+        global_add(a, &edep[nX0 + nY1 + Z1], w[6]);
+        global_add(a, &edep[nX1 + nY1 + Z1], w[7]);
+        wc.n_atomics += 8;
+    };
 
     // ---- deposits, the CBET kernels (ACC = false): every step's deposit goes to LDS during the NEXT step, in the shadow of
     // that step's record gather (:341-348: a_c * increment to the eight nodes, a_c = (Fz * Fy) * Fx).  What it needs
@@ -628,66 +704,54 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         wgt[5] = zy01 * Fx1;
         wgt[6] = zy11 * Fx0;
         wgt[7] = zy11 * Fx1;
-        if (inbox) lds_add8(wgt);
+        if (CBET_LANES(inbox_m)) lds_add8(wgt);
         // window misses: eight atomics, younger than the record gather just issued -- counted for its wait
-        wc.pend += any_missed ? 8 : 0;
-        if (any_missed && missed) {
-            const int nX0 = __mul24(X0, sXh), nX1 = __mul24(X1, sXh), nY0 = __mul24(Y0, sYh), nY1 = __mul24(Y1, sYh);
-            global_add(a, &edep[nX0 + nY0 + Z0], wgt[0]);
-            global_add(a, &edep[nX1 + nY0 + Z0], wgt[1]);
-            global_add(a, &edep[nX0 + nY0 + Z1], wgt[2]);
-            global_add(a, &edep[nX1 + nY0 + Z1], wgt[3]);
-            global_add(a, &edep[nX0 + nY1 + Z0], wgt[4]);
-            global_add(a, &edep[nX1 + nY1 + Z0], wgt[5]);
-            global_add(a, &edep[nX0 + nY1 + Z1], wgt[6]);
-            global_add(a, &edep[nX1 + nY1 + Z1], wgt[7]);
-            wc.n_atomics += 8;
-            ++wc.n_miss;
+        if (miss_m != 0ull) {
+            wc.pend += 8;
+            if (CBET_LANES(miss_m)) {
+                hbm_add8(wgt);
+                ++wc.n_miss;
+            }
         }
         if (CBET == 4) {
             // Displacement components: the ray's own node only -- box A's tiles, or HBM for a lane of
             // box B / outside the boxes.
+            const bool inbox = CBET_LANES(inbox_m);
             if (inbox && tile_off == 0) {
                 if (CBET_AUDIT(a, (unsigned)(own_slot + 2 * T::DT) < (unsigned)NLDS)) {
                     __hip_atomic_fetch_add(&s_val[own_slot], q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_fetch_add(&s_val[own_slot + T::DT], q2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_fetch_add(&s_val[own_slot + 2 * T::DT], q3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-            } else if (inbox || missed) {
+            } else if (inbox || CBET_LANES(miss_m)) {
                 global_add(a, &edep[a.comp_stride + own_node], q1);
                 global_add(a, &edep[2 * a.comp_stride + own_node], q2);
                 global_add(a, &edep[3 * a.comp_stride + own_node], q3);
                 wc.n_atomics += 3;
             }
         }
-        inbox = false;
-        missed = false;
-        any_missed = false;
+        inbox_m = 0ull;
+        miss_m = 0ull;
     };
 
     // ---- deposits, the plain trace (ACC = true): summed in registers while the ray's eight nodes stay the same ----------
     // The deposit of a step (:341-348: a_c * increment to the eight nodes, a_c = (Fz * Fy) * Fx) is ADDED TO THE LANE'S
     // PENDING SUMS S[8] at the end of the step; the sums go to LDS (or, for a lane outside both boxes, to HBM) only when
     // the ray's low corner changes, or the ray ends.  A ray keeps its eight nodes for 1.9 steps on average (256^3), so
-    // a ds_add_f64 carries 47 % of the lanes instead of all of them: the LDS pipeline -- the unit this kernel is bound
-    // by -- serves 133 instead of 188 cycles per wave-step (scripts/deposit_layouts.py).  The flush happens in the NEXT
-    // step, right after the new cell is known (in the shadow of its record gather) and BEFORE that step's window pass
-    // moves anything, i.e. while the boxes still stand where the last window pass put them for exactly these nodes.
+    // a ds_add_f64 carries 47 % of the lanes instead of all of them: the LDS pipeline serves 133 instead of 188 cycles per
+    // wave-step (scripts/deposit_layouts.py).  The flush happens in the NEXT step, right after the new cell is known (in
+    // the shadow of its record gather) and BEFORE that step's window pass moves anything, i.e. while the boxes still
+    // stand where the last window pass put them for exactly these nodes.
     double S[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // pending sums for the nodes X0..Z1
-    bool restart = false;                    // per lane: the sums went out in this step's flush and restart with its deposit
-    bool moved = true;                       // per lane: this step's relocation changed the ray's cell
+    unsigned long long restart_m = 0ull;     // lanes whose sums went out in this step's flush and restart with its deposit
     bool p_odd = true;                       // wave-uniform: the nodes came from the rare (non-negative offset) branch
     auto accumulate = [&]() {
-        // 14 products instead of the reference's 20: ((Fz * inc) * Fy) * Fx for ((Fz * Fy) * Fx) * inc -- three roundings
-        // either way, i.e. a deposit differs from the reference's by at most 2 ulp (the sum order of the atomics already
-        // moves a cell's total by more: SURVEY 8(c)'s metric is 1e-9).  The ray's own state (position, velocity, energy,
-        // cell: everything that decides where it goes and when it stops) keeps the reference's operations one for one.
+        // 14 products instead of the reference's 20 (see deposit_previous).  S * 1 + w and S * 0 + w are exact forms of
+        // "S + w" and "w": one fma each, written IN PLACE (left to the compiler it becomes v_fmac into the product's
+        // register and eight 64-bit copies back at the loop edge)
         const double zi0 = Fz0 * inc, zi1 = Fz1 * inc;
         const double zy00 = zi0 * Fy0, zy10 = zi1 * Fy0, zy01 = zi0 * Fy1, zy11 = zi1 * Fy1;
-        // order (x,y,z) = (0,0,0) (1,0,0) (0,0,1) (1,0,1) (0,1,0) (1,1,0) (0,1,1) (1,1,1) -- :341-348 without the flips
-        // S * 1 + w and S * 0 + w are exact forms of "S + w" and "w": one fma each, written IN PLACE (left to the
-        // compiler it becomes v_fmac into the product's register and eight 64-bit copies back at the loop edge)
-        const double k = restart ? 0.0 : 1.0;
+        const double k = CBET_LANES(restart_m) ? 0.0 : 1.0;
         auto add = [&](double &sum, double w) { asm("v_fma_f64 %0, %0, %1, %2" : "+v"(sum) : "v"(k), "v"(w)); };
         add(S[0], zy00 * Fx0);
         add(S[1], zy00 * Fx1);
@@ -698,35 +762,24 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         add(S[6], zy11 * Fx0);
         add(S[7], zy11 * Fx1);
     };
-    // changed: per lane, the ray's nodes are about to change (or the ray has ended)
-    auto flush_pending = [&](bool changed) {
-        const bool fl = changed && (inbox || missed);
-        if (CBET_BALLOT(fl) != 0ull) {   // scalar branch (taken in 99 % of the wave-steps: some lane always moves on)
-            if (fl && inbox) lds_add8(S);
+    // changed_m: lanes whose nodes are about to change (or whose ray has ended)
+    auto flush_pending = [&](unsigned long long changed_m) {
+        const unsigned long long fl_m = changed_m & (inbox_m | miss_m);
+        if (fl_m != 0ull) {   // scalar branch (taken in 99 % of the wave-steps: some lane always moves on)
+            if (CBET_LANES(fl_m & inbox_m)) lds_add8(S);
             // window misses: eight atomics, younger than the record gather just issued -- counted for its wait.  (Asked
             // only when the last window pass left some lane outside both boxes: 1 % of the wave-steps.)
-            const bool any_out = any_missed && CBET_BALLOT(fl && missed) != 0ull;
-            wc.pend += any_out ? 8 : 0;
-            if (any_out && fl && missed) {
-                const int nX0 = __mul24(X0, sXh), nX1 = __mul24(X1, sXh), nY0 = __mul24(Y0, sYh), nY1 = __mul24(Y1, sYh);
-                global_add(a, &edep[nX0 + nY0 + Z0], S[0]);
-                global_add(a, &edep[nX1 + nY0 + Z0], S[1]);
-                global_add(a, &edep[nX0 + nY0 + Z1], S[2]);
-                global_add(a, &edep[nX1 + nY0 + Z1], S[3]);
-                global_add(a, &edep[nX0 + nY1 + Z0], S[4]);
-                global_add(a, &edep[nX1 + nY1 + Z0], S[5]);
-                global_add(a, &edep[nX0 + nY1 + Z1], S[6]);
-                global_add(a, &edep[nX1 + nY1 + Z1], S[7]);
-                wc.n_atomics += 8;
+            if (miss_m != 0ull) {
+                const unsigned long long out_m = fl_m & miss_m;
+                wc.pend += out_m != 0ull ? 8 : 0;
+                if (CBET_LANES(out_m)) hbm_add8(S);
             }
         }
-        restart = fl;
+        restart_m = fl_m;
     };
 
-    for (int tt = 0; tt < a.nt; ++tt) {                        // :207
-        if (live == 0ull) break;
-        wc.steps_miss += 1u << 16;
-        tot_steps += __popcll(live);
+    for (int tt = 0; tt < a.nt; ++tt) {                        // :207  (live != 0 here: checked where lanes end)
+        if constexpr (STATS || kDiagClocks) wc.steps_miss += 1u << 16;
         // ---- move ------------------------------------------------------------------------------------------
         // :268-273 kick then drift (stencil values gathered during the previous step)
         s.vx -= rec_kxy.x;
@@ -744,9 +797,9 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         const double g0x = fx - fcx, g0y = fy - fcy, g0z = fz - fcz;
         const bool upx = g0x >= kNearTol, dnx = g0x < kNearTol - 1.0, upy = g0y >= kNearTol, dny = g0y < kNearTol - 1.0,
                    upz = g0z >= kNearTol, dnz = g0z < kNearTol - 1.0;
-        // wave-uniform: this step runs the general (face-aware) forms
-        slow = !deep || ((CBET_BALLOT(!(fabs(g0x) < kFarJump)) | CBET_BALLOT(!(fabs(g0y) < kFarJump)) |
-                                     CBET_BALLOT(!(fabs(g0z) < kFarJump))) & live) != 0ull;
+        // wave-uniform: this step runs the general (face-aware) forms.  One compare of the largest |g| (a NaN -- which
+        // moves no cell in either form -- is ignored by the maximum)
+        slow = !deep || (CBET_BALLOT(!(max_abs3(g0x, g0y, g0z) < kFarJump)) & live) != 0ull;
         // ---- relocate, gather -------------------------------------------------------------------
         // The deep-interior form updates the cell IN PLACE; the rare general form takes the update back first (kept as
         // copies for it, the old cell costs the common path three moves).
@@ -754,16 +807,18 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         s.ci += di;
         s.cj += dj;
         s.ck += dk;
-        if constexpr (ACC) moved = upx || dnx || upy || dny || upz || dnz;   // (the six compares, combined on the scalar unit)
         if (slow) {                        // near a face (or a far jump): closed form with the candidate bounds
             int oi = s.ci - di, oj = s.cj - dj, ok = s.ck - dk;
             asm volatile("" : "+v"(oi), "+v"(oj), "+v"(ok));   // (recomputed here, not carried from above the update)
             s.ci = relocate_closed(oi, fx, nx);
             s.cj = relocate_closed(oj, fy, ny);
             s.ck = relocate_closed(ok, fz, nz);
-            if constexpr (ACC) moved = s.ci != oi || s.cj != oj || s.ck != ok;
         }
-        cell = (unsigned)mad24(mad24(s.ci, ny, s.cj), nz, s.ck);
+        const unsigned new_cell = (unsigned)mad24(mad24(s.ci, ny, s.cj), nz, s.ck);
+        // lanes whose ray changed cell (ACC: their pending sums must leave): one compare with the cell it had
+        unsigned long long moved_m = 0ull;
+        if constexpr (ACC) moved_m = CBET_BALLOT(new_cell != cell);
+        cell = new_cell;
         // :296-298 absorption coefficient at the new node and the NEXT step's kicks
         gather_record();
         // (everything below reads the cell through this barrier, i.e. is scheduled BEHIND the gather's issue: left alone the
@@ -784,6 +839,18 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         // per zone the 16 lanes of rows 0-3 x columns 0-3 share a cell; bits 0 and 1 (column) and bit 3 (row)
         // give those 16 lanes all 8 orders, two lanes each.
         const double ox = (fx - fcx) - 0.5, oy = (fy - fcy) - 0.5, oz = (fz - fcz) - 0.5;   // :319-321
+        // Node indices.  The offsets are xtemp - thisx - 0.5 with |xtemp - thisx| < 0.5001, i.e. negative except in
+        // a 1e-4-wide sliver: when they are negative on every axis of every live lane (a ballot of the three sign
+        // compares: ~98 % of the wave-steps) the low corner is the own node minus one and the first-visited node
+        // depends on the lane's flip bits only.
+        const bool ngx = ox < 0, ngy = oy < 0, ngz = oz < 0;
+        const bool all_negative = (live & ~(CBET_BALLOT(ngx) & CBET_BALLOT(ngy) & CBET_BALLOT(ngz))) == 0ull;
+        // the pending sums leave for the nodes they belong to before those are replaced: a lane whose cell changed (the
+        // low corner is a function of the cell while the offsets are negative), every lane around the rare branch
+        if constexpr (ACC) {
+            flush_pending((all_negative && !p_odd) ? (~live | moved_m) : ~0ull);
+            p_odd = !all_negative;
+        }
         {
             // The two factors of an axis are d = 1 - |o| and 1 - d (:329-336); which of them comes first is the lane's
             // flip bit.  Without selects: F0 = +-(|o| - h), h = 1.0 with the sign flipped for a flipped lane (exactly
@@ -798,21 +865,9 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
             pair(oy, pfy, Fy0, Fy1);
             pair(oz, pfz, Fz0, Fz1);
         }
-        // Node indices.  The offsets are xtemp - thisx - 0.5 with |xtemp - thisx| < 0.5001, i.e. negative except in
-        // a 1e-4-wide sliver: when they are negative on every axis of every live lane (a ballot of the three sign
-        // compares: ~98 % of the wave-steps) the low corner is the own node minus one and the first-visited node
-        // depends on the lane's flip bits only.
         // the lane's low corner (haloed) relative to box A's origin: what the common case tests; the corner itself is
         // rebuilt from it where a box has to move (as a value of its own it costs three copies per step)
         int rx, ry, rz;
-        const bool ngx = ox < 0, ngy = oy < 0, ngz = oz < 0;
-        const bool all_negative = (live & ~(CBET_BALLOT(ngx) & CBET_BALLOT(ngy) & CBET_BALLOT(ngz))) == 0ull;
-        // the pending sums leave for the nodes they belong to before those are replaced: a lane whose cell changed (the
-        // low corner is a function of the cell while the offsets are negative), every lane around the rare branch
-        if constexpr (ACC) {
-            flush_pending(!alive || moved || !all_negative || p_odd);
-            p_odd = !all_negative;
-        }
         if (all_negative) {   // scalar branch
             rx = s.ci - oA.x;
             ry = s.cj - oA.y;
@@ -834,7 +889,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
             Y0 = ly + (hy ? 1 : 0); Y1 = ly + (hy ? 0 : 1);
             Z0 = lz + (hz ? 1 : 0); Z1 = lz + (hz ? 0 : 1);
         }
-        if (CBET && alive) {   // the gain gathers are memory accesses: live lanes only
+        if (CBET && CBET_LANES(live)) {   // the gain gathers are memory accesses: live lanes only
             // path length of the step; u_eff = the ray's energy averaged over the step
             double ds = 0.0;
             if (gk || CBET >= 2) ds = sqrt_speed(s.vx * s.vx + s.vy * s.vy + s.vz * s.vz) * a.dt;
@@ -876,80 +931,93 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
             }
         }
         // ---- windows ----------------------------------------------------------------------------------
-        inbox = alive;         // the lane deposits into LDS this step ...
-        // ... into the tile at tile_off (in doubles): 0 whenever box B is idle -- every path that retires B leaves it so
-        if constexpr (ACC) any_missed = false;   // ... and no lane lies outside both boxes, unless the window pass finds one
-        {
-            // Common case, decided with three compares: every live lane's eight target nodes lie inside its home box
-            // -- nothing has to move.  (The boxes follow on demand: the step in which a lane leaves is the step in
-            // which its box is shifted, before anything is deposited.)
-            const unsigned long long memA = live & ~hbm, memB = live & hbm;
-            unsigned long long out_core = memA & ~(CBET_BALLOT((unsigned)rx <= (unsigned)T::SX) & CBET_BALLOT((unsigned)ry <= (unsigned)T::SY) &
-                                                   CBET_BALLOT((unsigned)rz <= (unsigned)T::SZ));
-            if (b_active) {   // scalar branch
-                asm volatile("");   // (a real branch: if-converted, its assignments cost the common path two selects)
-                wc.slabs_bsteps += 1u;
-                const int abx = oA.x - oB.x, aby = oA.y - oB.y, abz = oA.z - oB.z;
-                out_core |= memB & ~(CBET_BALLOT((unsigned)(rx + abx) <= (unsigned)TB::SX) &
-                                     CBET_BALLOT((unsigned)(ry + aby) <= (unsigned)TB::SY) &
-                                     CBET_BALLOT((unsigned)(rz + abz) <= (unsigned)TB::SZ));
-                tile_off = homeB ? T::N : 0;
-            }
-            if (out_core != 0ull) {
-                const int lx = rx + oA.x, ly = ry + oA.y, lz = rz + oA.z;   // (before box A moves)
-                // box A follows the lanes whose home it is
-                follow_box<T, NC>(a, tileA, oA, memA, lx, ly, lz, lane, edep, sXh, sYh, wc, NSLOT, a.comp_stride);
-                const unsigned long long lost_mask =
-                    memA & ~(CBET_BALLOT((unsigned)(lx - oA.x) <= (unsigned)T::SX) & CBET_BALLOT((unsigned)(ly - oA.y) <= (unsigned)T::SY) &
-                             CBET_BALLOT((unsigned)(lz - oA.z) <= (unsigned)T::SZ));
-                if (lost_mask == 0ull && !b_active) {
-                    // the usual outcome: A moved and holds every live lane again (inbox = alive, tile_off = 0 stand)
-                    deep = box_deep_inside<T>(oA, nx, ny, nz);
-                } else {
-                    const bool inA = alive && holds<T>(oA, lx, ly, lz);
-                    const bool lost = alive && !homeB && !inA;
-                    // lanes that fell out of A look for a home in B, which follows its own lanes only (letting it chase the
-                    // lost ones as well was measured: more misses, 0.63 % against 0.48 % of the ray-steps); an idle B is
-                    // re-created around the first lost lane
-                    if (b_active) {  // scalar branch
-                        follow_box<TB, 1>(a, tileB, oB, memB, lx, ly, lz, lane, edep, sXh, sYh, wc, 0, 0);
-                    } else if (lost_mask != 0ull) {
-                        const int src = __ffsll((long long)lost_mask) - 1;
-                        const int sx = __builtin_amdgcn_readlane(lx, src), sy = __builtin_amdgcn_readlane(ly, src),
-                                  sz = __builtin_amdgcn_readlane(lz, src);
-                        oB.x = sx - (TB::WX / 2 - 1);
-                        oB.y = sy - (TB::WY / 2 - 1);
-                        oB.z = sz - TB::SZ / 2;
-                        b_active = true;  // its tile is all zero: zeroed at start and flushed whenever it empties
-                    }
-                    const bool inB = alive && holds<TB>(oB, lx, ly, lz);
-                    homeB = homeB || (lost && inB);
-                    // a B lane that drifted out of B but back into A goes home
-                    if (alive && homeB && !inB && inA) homeB = false;
-                    hbm = CBET_BALLOT(alive && homeB);
-                    if (hbm == 0ull) {
-                        __builtin_amdgcn_wave_barrier();
-                        flush_box<TB, 1>(a, tileB, oB, lane, edep, sXh, sYh, wc, 0, 0);
-                        b_active = false;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    const bool useB = alive && homeB && inB;
-                    inbox = useB || (alive && !homeB && inA);
-                    tile_off = useB ? T::N : 0;
-                    any_missed = CBET_BALLOT(alive && !inbox) != 0ull;
-                    if (any_missed) wc.steps_miss += 1u;
-                    if (ACC && alive && !inbox) ++wc.n_miss;   // ray-steps whose deposit is bound for HBM (ACC: counted here, the
-                                                               // only place a lane can come to lie outside both boxes)
-                    deep = !any_missed && box_deep_inside<T>(oA, nx, ny, nz) && (!b_active || box_deep_inside<TB>(oB, nx, ny, nz));
-                }
-                // (the write-back paths keep the count in a vector register; the common path's stays scalar this way)
-                wc.pend = __builtin_amdgcn_readfirstlane(wc.pend);
-            } else if (!deep) {
-                deep = box_deep_inside<T>(oA, nx, ny, nz) && (!b_active || box_deep_inside<TB>(oB, nx, ny, nz));
-            }
+        // Common case, decided with three compares: every live lane's eight target nodes lie inside its home box
+        // -- nothing has to move: the lanes deposit into LDS (inbox_m = live), box A's while box B is idle (tile_off = 0:
+        // every path that retires B leaves it so), and none lies outside both boxes.  (The boxes follow on demand: the
+        // step in which a lane leaves is the step in which its box is shifted, before anything is deposited.)
+        inbox_m = live;
+        const unsigned long long memA = live & ~hbm;
+        unsigned long long out_core = memA & ~(CBET_BALLOT((unsigned)rx <= (unsigned)T::SX) & CBET_BALLOT((unsigned)ry <= (unsigned)T::SY) &
+                                               CBET_BALLOT((unsigned)rz <= (unsigned)T::SZ));
+        if (b_active) {   // scalar branch
+            asm volatile("");   // (a real branch: if-converted, its assignments cost the common path two selects)
+            if constexpr (STATS) wc.slabs_bsteps += 1u;
+            const int abx = oA.x - oB.x, aby = oA.y - oB.y, abz = oA.z - oB.z;
+            out_core |= hbm & ~(CBET_BALLOT((unsigned)(rx + abx) <= (unsigned)TB::SX) &
+                                CBET_BALLOT((unsigned)(ry + aby) <= (unsigned)TB::SY) &
+                                CBET_BALLOT((unsigned)(rz + abz) <= (unsigned)TB::SZ));
+            tile_off = CBET_LANES(hbm) ? T::N : 0;
         }
-    
-        missed = alive && !inbox;
+        if (out_core != 0ull) {
+#ifdef CBET_DIAG_CLOCKS
+            unsigned long long dg_t0;
+            asm volatile("s_memtime %0" : "=&s"(dg_t0) : : "memory");
+#endif
+            const bool alive = CBET_LANES(live);
+            const int lx = rx + oA.x, ly = ry + oA.y, lz = rz + oA.z;   // (before box A moves)
+            // box A follows the lanes whose home it is
+            follow_box<T, NC>(a, tileA, oA, memA, lx, ly, lz, lane, edep, sXh, sYh, wc, NSLOT, a.comp_stride);
+            const unsigned long long lost_mask =
+                memA & ~(CBET_BALLOT((unsigned)(lx - oA.x) <= (unsigned)T::SX) & CBET_BALLOT((unsigned)(ly - oA.y) <= (unsigned)T::SY) &
+                         CBET_BALLOT((unsigned)(lz - oA.z) <= (unsigned)T::SZ));
+            if (lost_mask == 0ull && !b_active) {
+                // the usual outcome: A moved and holds every live lane again (inbox_m = live, tile_off = 0 stand)
+                deep = box_deep_inside<T>(oA, nx, ny, nz);
+            } else {
+                bool homeB = CBET_LANES(hbm);
+                const bool inA = alive && holds<T>(oA, lx, ly, lz);
+                const bool lost = alive && !homeB && !inA;
+                // lanes that fell out of A look for a home in B, which follows its own lanes only (letting it chase the
+                // lost ones as well was measured: more misses, 0.63 % against 0.48 % of the ray-steps); an idle B is
+                // re-created around the first lost lane
+                if (b_active) {  // scalar branch
+                    follow_box<TB, 1>(a, tileB, oB, hbm, lx, ly, lz, lane, edep, sXh, sYh, wc, 0, 0);
+                } else if (lost_mask != 0ull) {
+                    const int src = __ffsll((long long)lost_mask) - 1;
+                    const int sx = __builtin_amdgcn_readlane(lx, src), sy = __builtin_amdgcn_readlane(ly, src),
+                              sz = __builtin_amdgcn_readlane(lz, src);
+                    oB.x = sx - (TB::WX / 2 - 1);
+                    oB.y = sy - (TB::WY / 2 - 1);
+                    oB.z = sz - TB::SZ / 2;
+                    b_active = true;  // its tile is all zero: zeroed at start and flushed whenever it empties
+                }
+                const bool inB = alive && holds<TB>(oB, lx, ly, lz);
+                homeB = homeB || (lost && inB);
+                // a B lane that drifted out of B but back into A goes home
+                if (alive && homeB && !inB && inA) homeB = false;
+                hbm = CBET_BALLOT(alive && homeB);
+                if (hbm == 0ull) {
+                    __builtin_amdgcn_wave_barrier();
+                    flush_box<TB, 1>(a, tileB, oB, lane, edep, sXh, sYh, wc, 0, 0);
+                    b_active = false;
+                }
+                __builtin_amdgcn_wave_barrier();
+                const bool useB = alive && homeB && inB;
+                tile_off = useB ? T::N : 0;
+                inbox_m = CBET_BALLOT(useB || (alive && !homeB && inA));
+                const bool any_missed = (live & ~inbox_m) != 0ull;
+                if constexpr (STATS) {
+                    if (any_missed) wc.steps_miss += 1u;
+                    if (ACC && alive && !CBET_LANES(inbox_m)) ++wc.n_miss;   // ray-steps whose deposit is bound for HBM (ACC: counted
+                                                                            // here, the only place a lane can come to lie outside both boxes)
+                }
+                deep = !any_missed && box_deep_inside<T>(oA, nx, ny, nz) && (!b_active || box_deep_inside<TB>(oB, nx, ny, nz));
+            }
+            // (the write-back paths keep the count in a vector register; the common path's stays scalar this way)
+            wc.pend = __builtin_amdgcn_readfirstlane(wc.pend);
+#ifdef CBET_DIAG_CLOCKS
+            {
+                unsigned long long dg_t1;
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(dg_t1) : "s"(dg_t0) : "memory");
+                dg_shift += dg_t1 - dg_t0;
+                dg_nshift += 1;
+            }
+#endif
+            miss_m = live & ~inbox_m;
+        } else {
+            if (!deep) deep = box_deep_inside<T>(oA, nx, ny, nz) && (!b_active || box_deep_inside<TB>(oB, nx, ny, nz));
+            miss_m = 0ull;
+        }
         // ---- absorption (:305-311) ---------------------------------------------------------------------
         await_record();   // the record gathered after the relocation: kappa now, the kicks at the top of the next step
         if (absorb) {
@@ -969,17 +1037,21 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
             const double *b = a.bounds;  // {xlo, xhi, ylo, yhi, zlo, zhi}
             died |= CBET_BALLOT(s.px < b[0]) | CBET_BALLOT(s.px > b[1]) | CBET_BALLOT(s.py < b[2]) |
                     CBET_BALLOT(s.py > b[3]) | CBET_BALLOT(s.pz < b[4]) | CBET_BALLOT(s.pz > b[5]);
-            alive = alive && !(s.uray <= s.ustop || s.px < b[0] || s.px > b[1] || s.py < b[2] || s.py > b[3] || s.pz < b[4] || s.pz > b[5]);
-        } else {
-            alive = alive && !(s.uray <= s.ustop);
         }
-        live &= ~died;
-        hbm &= live;
+        died &= live;
+        if (died != 0ull) {   // scalar branch: some ray ended in this step, its tt + 1-th
+            asm volatile("");
+            tot_steps += __popcll(died) * (tt + 1);
+            live &= ~died;
+            hbm &= live;
+            if (live == 0ull) break;
+        }
         __builtin_amdgcn_wave_barrier();
     }
+    tot_steps += __popcll(live) * a.nt;      // rays that ran out of steps (:207)
 
     // every lane's pending sums (or the last step's deposit), then whatever is still in LDS
-    if constexpr (ACC) flush_pending(true);
+    if constexpr (ACC) flush_pending(~0ull);
     else deposit_previous();
     __syncthreads();
     flush_box<T, NC>(a, tileA, oA, lane, edep, sXh, sYh, wc, NSLOT, a.comp_stride);
@@ -991,18 +1063,36 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, kWave);
         if (lane == 0 && t != 0.0) atomicAdd(&a.beam_gain[beam], t);
     }
+#ifdef CBET_DIAG_CLOCKS
+    if (lane == 0) {   // the diagnostic build reuses four slots: record-wait cycles, shift-path cycles, shift entries, wave cycles
+        unsigned long long dg_t_end;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(dg_t_end) : : "memory");
+        atomicAdd(&a.counters[kCntSteps], (unsigned long long)tot_steps);
+        atomicAdd(&a.counters[kCntWaveSteps], (unsigned long long)(wc.steps_miss >> 16));
+        atomicAdd(&a.counters[kCntGlobalAtomics], dg_wait);
+        atomicAdd(&a.counters[kCntEvictions], dg_shift);
+        atomicAdd(&a.counters[kCntWaveStepsWide], dg_nshift);
+        atomicAdd(&a.counters[kCntSlabsRetired], dg_t_end - dg_t_start);
+        atomicAdd(&a.counters[kCntRays], wc.dg_ret);              // (the ray count gives way to the write-backs' clocks ...)
+        atomicAdd(&a.counters[kCntWaveStepsMiss], wc.dg_nret);    // (... and their number)
+    }
+    return;
+#endif
     // counters: one atomic per wave and counter
-    const int tot_rays = wave_sum(launched), tot_at = wave_sum(wc.n_atomics),
-              tot_miss = wave_sum(wc.n_miss);
+    if constexpr (STATS) {
+        const int tot_at = wave_sum(wc.n_atomics), tot_miss = wave_sum(wc.n_miss);
+        if (lane == 0) {
+            atomicAdd(&a.counters[kCntGlobalAtomics], (unsigned long long)tot_at);
+            atomicAdd(&a.counters[kCntEvictions], (unsigned long long)tot_miss);
+            atomicAdd(&a.counters[kCntWaveSteps], (unsigned long long)(wc.steps_miss >> 16));
+            atomicAdd(&a.counters[kCntWaveStepsMiss], (unsigned long long)(wc.steps_miss & 0xFFFFu));
+            atomicAdd(&a.counters[kCntWaveStepsWide], (unsigned long long)(wc.slabs_bsteps & 0xFFFFu));
+            atomicAdd(&a.counters[kCntSlabsRetired], (unsigned long long)(wc.slabs_bsteps >> 16));
+        }
+    }
     if (lane == 0) {
         atomicAdd(&a.counters[kCntSteps], (unsigned long long)tot_steps);
         atomicAdd(&a.counters[kCntRays], (unsigned long long)tot_rays);
-        atomicAdd(&a.counters[kCntGlobalAtomics], (unsigned long long)tot_at);
-        atomicAdd(&a.counters[kCntEvictions], (unsigned long long)tot_miss);
-        atomicAdd(&a.counters[kCntWaveSteps], (unsigned long long)(wc.steps_miss >> 16));
-        atomicAdd(&a.counters[kCntWaveStepsMiss], (unsigned long long)(wc.steps_miss & 0xFFFFu));
-        atomicAdd(&a.counters[kCntWaveStepsWide], (unsigned long long)(wc.slabs_bsteps & 0xFFFFu));
-        atomicAdd(&a.counters[kCntSlabsRetired], (unsigned long long)(wc.slabs_bsteps >> 16));
     }
 }
 
@@ -1017,19 +1107,21 @@ hipError_t launch_trace_window(const TraceArgs &a, bool force_idx64, hipStream_t
     // with the CBET hooks, for gain grids of >= 2^32 bytes (32-bit byte offsets otherwise)
     const bool generic = force_idx64 || (a.gain && 8ull * (unsigned long long)a.hsize >= (1ull << 32)) || a.absorption != 1 ||
                          sizeof(StepRecord) * (unsigned long long)a.nx * a.ny * a.nz > (1ull << 32);
-    if (a.quantity == 1) {  // the fused four-component field pass (single z-planes: four tiles per wave must fit)
-        if (generic) hipLaunchKernelGGL((k_trace_window<8, true, 4>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((k_trace_window<8, false, 4>), grid, block, 0, stream, a);
-    } else if (a.quantity == 2) {  // the energy field alone: the shipped kernel's windows, energy x path length deposited
-        if (generic) hipLaunchKernelGGL((k_trace_window<16, true, 2>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((k_trace_window<16, false, 2>), grid, block, 0, stream, a);
-    } else if (a.gain || a.beam_gain) {
-        if (generic) hipLaunchKernelGGL((k_trace_window<16, true, 1>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((k_trace_window<16, false, 1>), grid, block, 0, stream, a);
-    } else {
-        if (generic) hipLaunchKernelGGL((k_trace_window<16, true, 0>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((k_trace_window<16, false, 0>), grid, block, 0, stream, a);
-    }
+    auto go = [&](auto wz, auto cbet) {
+        constexpr int WZ = decltype(wz)::value, CB = decltype(cbet)::value;
+        if (a.stats) {      // cbet_params.window_stats: the instantiation that also counts the window diagnostics
+            if (generic) hipLaunchKernelGGL((k_trace_window<WZ, true, CB, true>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((k_trace_window<WZ, false, CB, true>), grid, block, 0, stream, a);
+        } else {
+            if (generic) hipLaunchKernelGGL((k_trace_window<WZ, true, CB, false>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((k_trace_window<WZ, false, CB, false>), grid, block, 0, stream, a);
+        }
+    };
+    using std::integral_constant;
+    if (a.quantity == 1) go(integral_constant<int, 8>{}, integral_constant<int, 4>{});        // the fused four-component field pass (single z-planes: four tiles per wave must fit)
+    else if (a.quantity == 2) go(integral_constant<int, 16>{}, integral_constant<int, 2>{});  // the energy field alone: the shipped kernel's windows, energy x path length deposited
+    else if (a.gain || a.beam_gain) go(integral_constant<int, 16>{}, integral_constant<int, 1>{});
+    else go(integral_constant<int, 16>{}, integral_constant<int, 0>{});
     return hipGetLastError();
 }
 

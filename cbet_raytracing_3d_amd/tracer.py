@@ -67,8 +67,9 @@ class RayTracer:
         return torch.zeros(shape, dtype=torch.float64, device=self.device)
 
     def launch(self, edep, shard_index=0, shard_count=1, beam_lo=0, beam_hi=None,
-               kernel_variant=None, force_wide_index=None, use_host_trig=True):
-        """Enqueue one launch_ray_XYZ on torch's current stream, accumulating into `edep`."""
+               kernel_variant=None, force_wide_index=None, use_host_trig=True, stats=None):
+        """Enqueue one launch_ray_XYZ on torch's current stream, accumulating into `edep`.  stats=True: the launch also
+        counts the deposit windows' diagnostics (cbet_params.window_stats; a timed launch does not)."""
         per_beam = edep.dim() == 4
         want = ((self.params.nbeams,) + self.grid_shape) if per_beam else self.grid_shape
         # a single grid whose rows are longer than nz + 2 is a padded grid (new_grid(zpitch=...))
@@ -82,6 +83,8 @@ class RayTracer:
             p.kernel_variant = kernel_variant
         if force_wide_index is not None:
             p.force_wide_index = force_wide_index
+        if stats is not None:
+            p.window_stats = 1 if stats else 0
         d = self.derived
         stream = torch.cuda.current_stream(self.device).cuda_stream
         api.launch_ray_XYZ(0, d.nindices, self.d_te, self.d_r, self.d_ne, edep,
@@ -342,6 +345,21 @@ class SweepPipeline:
         torch.cuda.synchronize(tr.device)
         return sum(times[1:]) / reps
 
+    def window_diagnostics(self):
+        """The counters of ONE un-timed trace launch of this rank's share with cbet_params.window_stats = 1: the deposit
+        windows' diagnostics (wave-steps, window misses, box-B steps, planes retired, global atomics) that the timed
+        launches do not count.  Call it after counters(): it resets the contexts' counters; the last pass's slab stays."""
+        tr, d = self.tr, self.tr.derived
+        self.finish()
+        self.counters(reset=True)
+        scratch = torch.zeros_like(self.grids[0])
+        with torch.cuda.stream(self.s_trace[0]):
+            st = self.s_trace[0].cuda_stream
+            api.trace_nodes(0, d.nindices, None, None, scratch, tr.d_bbeam_norm, tr.d_beam_norm, tr.d_pow_r, tr.d_phase_r,
+                            d.xconst, d.yconst, d.zconst, self.launch_p.copy(window_stats=1), self.ctx[0], st)
+        torch.cuda.synchronize(tr.device)
+        return self.ctx[0].counters(self.s_trace[0].cuda_stream, True)
+
     def warm(self):
         """Run the combine once on the (zero) buffers: RCCL builds its communicator, channels and staging buffers on
         the first collective of a kind -- set-up, like the reference's cudaMalloc in its Init phase (main.cu:131-152),
@@ -427,6 +445,12 @@ class _DeviceCbetEngine:
         self.s_trace = [torch.cuda.Stream(device=dev) for _ in range(self.trace_streams)]
         self._launches = 0
         tr.tabulate()
+        # the step records too, HERE and on this stream: left to the first launch they are built lazily on THAT launch's
+        # trace stream, and the launches of the other rotating streams -- which only wait for ev_ready and see the host-side
+        # version already bumped -- would read the table while k_step_table is still writing it (a fresh context: garbage)
+        d = tr.derived
+        api.prepare_step_records(tr.ctx, tr.params, None, None, d.xconst, d.yconst, d.zconst,
+                                 torch.cuda.current_stream(dev).cuda_stream)
         self.ev_ready = torch.cuda.Event()
         self.ev_ready.record(torch.cuda.current_stream(dev))
 
@@ -1071,6 +1095,7 @@ def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_s
     # uses the field arrays as scratch and resets the counters: before the first field pass.)
     support = engine.support_mask() if (sparse and hasattr(engine, "support_mask") and (world_size > 1 or force)) else None
     slabs, pieces, plan = None, None, None
+    allocated = None    # event behind the first-pass allocation (zero-fill) of the slab arrays
     G = len(groups)
     gain_ev = [None] * G
     owed = []           # groups whose gain of the previous pass has not been sent back yet (it goes out between this pass's traces)
@@ -1121,16 +1146,21 @@ def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_s
                 plan = SegmentPlan(support, beams, slabs, rank, world_size, group, engine.slab_fields[0].device)
                 support = None
                 xch.use_plan(plan)
+            # begin_slab / use_plan zero-fill their arrays on THIS stream, which has just been made to wait for every trace
+            # group; the exchanges below run on the communication stream and wait for their own group's trace only -- without
+            # this event group 0's fields would land in slab_fields before the (late) fill and be zeroed by it
+            allocated = mark()
             first = 0
         else:
             first = G - LAG
         if plan is not None:
             xch.run_sparse(engine.own_fields, lambda s_: (slice(0, len(comps)), slice(None), slice(*slabs[s_])),
                            engine.slab_fields[0], lambda q: (slice(0, len(comps)), slice(*beams[q])), True,
-                           ncomp=len(comps), after=traced)
+                           ncomp=len(comps), after=list(traced) + [allocated])
         else:
             for k in range(first, G):
-                xch.fields_out(engine.own_fields, engine.slab_fields, *groups[k], comps, after=(traced[k],))
+                xch.fields_out(engine.own_fields, engine.slab_fields, *groups[k], comps, after=(traced[k], allocated))
+        allocated = None
         wait_here([xch.fence()])                     # every beam's fields over my slab are in
         ch = engine.update_gain_slab(not full)
         updated = mark()

@@ -100,6 +100,11 @@ typedef struct cbet_params {
                                  /* record table's decides 10 % of the pass time with dense rows of 258 doubles  */
                                  /* (16.9 ... 18.6 ms from one process to the next) and 2 % with rows of 264      */
                                  /* (DESIGN.md section 4.4).  Plain path only.                                    */
+    int window_stats;            /* 0 (default): a launch of the default kernel counts ray_steps and rays_traced  */
+                                 /* only.  1: the instantiation that also counts the deposit windows' diagnostics  */
+                                 /* (global_atomics, lds_evictions, wave_steps, wave_steps_miss, wave_steps_wide,  */
+                                 /* slabs_retired) -- a few scalar instructions per step that a timed launch does  */
+                                 /* not need.  The cross-check kernels (variants 1, 2) always count what they count. */
 } cbet_params;
 
 /* Quantities the reference derives in def.cuh / main.cu:156-161, evaluated in the same order. */

@@ -9,7 +9,7 @@ for n in "$@"; do
   if [ ! -f build_alt/libcbet_${n}_audit.so ]; then echo "$n SKIPPED: no audited twin (python scripts/build_variant.py $n)"; continue; fi
   if ! CBET_LIB_PATH=$PWD/build_alt/libcbet_${n}_audit.so timeout -k 10 300 python3 scripts/audit_variant.py > gpurun_out/alt/$n.audit 2>&1; then
     echo "$n NOT TIMED: the audited build failed or reported out-of-range accesses"; tail -4 gpurun_out/alt/$n.audit; continue; fi
-  CBET_LIB_PATH=$PWD/build_alt/libcbet_$n.so timeout -k 10 120 python3 bench.py --steps 10 --warmup 3 --no-cbet --no-cpu-baseline > gpurun_out/alt/$n.json 2> gpurun_out/alt/$n.err || { echo "$n FAILED"; tail -3 gpurun_out/alt/$n.err; continue; }
+  CBET_LIB_PATH=$PWD/build_alt/libcbet_$n.so timeout -k 10 120 python3 bench.py --steps 10 --warmup 3 --no-cbet --no-cpu-baseline --dense-samples 0 > gpurun_out/alt/$n.json 2> gpurun_out/alt/$n.err || { echo "$n FAILED"; tail -3 gpurun_out/alt/$n.err; continue; }
   python3 - "$n" <<'PY'
 import json,sys
 n=sys.argv[1]; d=json.load(open("gpurun_out/alt/%s.json"%n)); r=d["roofline"]

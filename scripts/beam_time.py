@@ -7,7 +7,7 @@ from cbet_raytracing_3d_amd import api
 from cbet_raytracing_3d_amd.tracer import RayTracer
 r, ne, te = api.load_s83177()
 bn = api.omega60_beam_norm()
-tr = RayTracer(api.default_params(256), r, ne, te)
+tr = RayTracer(api.default_params(256, window_stats=1), r, ne, te)   # (the window diagnostics are counted on request)
 e = tr.new_grid(zpitch=True)
 res = []
 for b in range(60):

@@ -9,7 +9,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 with_gain = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 r, ne, te = api.load_s83177()
-tr = RayTracer(api.default_params(n), r, ne, te)
+tr = RayTracer(api.default_params(n, window_stats=1), r, ne, te)
 gp = api.default_gain_params()
 tr.tabulate()
 f = tr.new_fields()

@@ -48,6 +48,8 @@ if os.path.exists(os.path.join(src, "cbet_rank_share.log")):
 
 
 def short(k):
+    if "k_trace_window" in k and ", true>(" in k:      # bench.py's un-timed diagnostic launch (cbet_params.window_stats)
+        return None
     for name in ("k_trace_window", "k_step_table", "k_tabulate"):
         if name in k:
             return k[k.index(name):].split("(")[0] if name == "k_trace_window" else name

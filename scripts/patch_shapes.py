@@ -15,7 +15,7 @@ from cbet_raytracing_3d_amd.tracer import RayTracer
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 r, ne, te = api.load_s83177()
-p = api.default_params(n, rim_merge=0)
+p = api.default_params(n, rim_merge=0, window_stats=1)
 d = api.derive(p)
 base = api.live_ray_list(p).reshape(-1, 64)
 rpz, zx = p.rays_per_zone, d.zones_spanned

@@ -6,7 +6,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 TAG=$1; OUT=gpurun_out/$TAG; mkdir -p "$OUT"
 timeout -k 10 400 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "parity_64 or truth_100 or window_kernel or nonuniform or sharding or wide_index_path or beam_resolved" > "$OUT/tests.log" 2>&1
 echo "tests rc=$?"; tail -2 "$OUT/tests.log"
-timeout -k 10 120 python bench.py --steps 10 --warmup 3 --no-cbet --no-cpu-baseline > "$OUT/bench.json" 2> "$OUT/bench.err"
+timeout -k 10 120 python bench.py --steps 10 --warmup 3 --no-cbet --no-cpu-baseline --dense-samples 0 > "$OUT/bench.json" 2> "$OUT/bench.err"
 python - "$OUT/bench.json" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1])); r = d["roofline"]

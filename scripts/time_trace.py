@@ -14,10 +14,10 @@ e = tr.new_grid()
 ts = []
 for k in range(reps + 3):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e.zero_(); tr.counters(reset=True); a.record(); tr.launch(e); b.record(); torch.cuda.synchronize()
+    e.zero_(); tr.counters(reset=True); a.record(); tr.launch(e, stats=bool(int(os.environ.get('CBET_STATS', '0')))); b.record(); torch.cuda.synchronize()
     if k >= 3:
         ts.append(a.elapsed_time(b))
 c = tr.counters(reset=True)
 print("%s: trace %.3f ms mean, %.3f min, %.3f max over %d launches; edep_sum %.10e steps %d atomics/step %.4f" % (
     os.path.basename(os.environ.get("CBET_LIB_PATH", "shipped")), sum(ts) / len(ts), min(ts), max(ts), len(ts), float(e.sum().item()), c.ray_steps,
-    c.global_atomics / c.ray_steps))
+    c.global_atomics / max(1, c.ray_steps)))

@@ -425,6 +425,57 @@ def test_slab_owned_loop_on_one_rank_equals_the_plain_loop(api, setup, torch_cud
     assert r2["workspace_bytes"] == api.cbet_slab_workspace_bytes(tr.params, 1, 0) - 8 * (2 + api.MAX_CBET_BEAMS)
 
 
+def test_slab_loop_as_first_use_of_a_fresh_tracer(api, inputs, torch_cuda):
+    """The slab loop's trace groups rotate over four streams that only wait for begin_beams' `ev_ready`: the step-record
+    table must be built (not just the node tables) before that event, or -- in a FRESH context, whose record memory is
+    uninitialised -- the launches of streams 1..3 read it while k_step_table is still writing it on stream 0.  A solve
+    with trace_groups > 1 as the very first use of a new RayTracer must equal the all-reduce loop of another."""
+    from cbet_raytracing_3d_amd.tracer import RayTracer
+    bn, r, ne, te = inputs
+    n, beams = 64, [0, 9, 16, 29, 38, 47, 55, 58]
+    gp = api.default_gain_params(tolerance=1e-6, max_passes=6, relax=1.0)
+    fresh = RayTracer(api.default_params(n, nbeams=len(beams)), r, ne, te, beam_norm=bn[beams])
+    e2 = fresh.new_grid()
+    r2 = fresh.cbet_solve(e2, gp, slabs=True, trace_groups=4)      # first thing this context ever runs
+    torch_cuda.cuda.synchronize()
+    other = RayTracer(api.default_params(n, nbeams=len(beams)), r, ne, te, beam_norm=bn[beams])
+    e1 = other.new_grid()
+    r1 = other.cbet_solve(e1, gp)
+    torch_cuda.cuda.synchronize()
+    assert r1["passes"] == r2["passes"]
+    assert parity_err(e2.cpu().numpy(), e1.cpu().numpy()) < 1e-9
+    fresh.close()
+    other.close()
+
+
+def test_slab_loop_first_pass_fields_survive_the_allocation(api, inputs, torch_cuda):
+    """With a communication stream (RCCL, or the stand-in transport used here) the first pass's exchanges run on that
+    stream behind their own group's trace only, while the slab arrays are allocated -- zero-filled -- on the caller's
+    stream behind ALL traces: the exchanges must also wait for the fill, or the fields that landed early are zeroed.
+    One rank, a stand-in transport with nothing to move (the own-part copies still run on the communication stream):
+    slab_fields after pass 0 must equal the whole-grid fields of the same beams."""
+    from cbet_raytracing_3d_amd.tracer import RayTracer, _DeviceCbetEngine, cbet_fixed_point_slabs
+    bn, r, ne, te = inputs
+    n, beams = 96, list(range(0, 60, 4))
+    tr = RayTracer(api.default_params(n, nbeams=len(beams)), r, ne, te, beam_norm=bn[beams])
+    gp = api.default_gain_params(tolerance=1e-30, max_passes=1, relax=1.0)      # exactly one (direction-building) pass
+    eng = _DeviceCbetEngine(tr, tr.new_grid(), gp)
+    eng.emulate_transport = lambda xch, sends, recvs: None
+    snap = {}
+    update = eng.update_gain_slab
+
+    def spy(frozen=False):          # (the update normalises the fields in place: look at them just before)
+        snap["slab"] = eng.slab_fields[0].clone()
+        snap["own"] = eng.own_fields.clone()
+        return update(frozen)
+    eng.update_gain_slab = spy
+    cbet_fixed_point_slabs(eng, gp, len(beams), tr.grid_shape[0], trace_groups=4)
+    torch_cuda.cuda.synchronize()
+    assert float(snap["own"][0].abs().sum()) > 0.0
+    assert torch_cuda.equal(snap["slab"], snap["own"])
+    tr.close()
+
+
 def test_config3_cbet_solve_256_properties(api, inputs, torch_cuda):
     """BASELINE config 3's "full CBET gain iteration": 256^3, 60 beams, the native fixed-point loop with the
     default gain parameters (the run bench.py reports in its `cbet` object).  Parity unpinned (no reference CBET

@@ -352,8 +352,9 @@ def test_full_grid_parity_256_default_kernel(api, oracle, inputs, torch_cuda):
     assert e.max() == pytest.approx(4.0037106759e13, rel=1e-10)
     assert np.count_nonzero(e) == 17053618 and e.size == 17173512
     assert np.array_equal(e == 0, oe == 0)                                       # the over-critical core stays exactly 0
-    e0, c0 = run(tr, torch_cuda)                                                 # kernel_variant = 0 (auto) is the same kernel
-    assert c0.ray_steps == c.ray_steps and c0.global_atomics < c.ray_steps
+    e0, c0 = run(tr, torch_cuda, stats=True)                                     # kernel_variant = 0 (auto) is the same kernel
+    assert c0.ray_steps == c.ray_steps and 0 < c0.global_atomics < c.ray_steps
+    assert c.global_atomics == 0 and c.wave_steps == 0                           # (window diagnostics only on request)
     assert parity_err(e0, oe) < PARITY_TOL
     tr.close()
 
@@ -367,7 +368,7 @@ def test_config5_as_stated_512_six_rays_per_zone(api, inputs, torch_cuda):
     tr = make_tracer(api, inputs, 512, rays_per_zone=6)
     d = tr.derived
     assert (d.nrays_x, d.nrays, d.nt) == (1062, 1062 * 1062, 2048)
-    e3, c3 = run(tr, torch_cuda, kernel_variant=3)
+    e3, c3 = run(tr, torch_cuda, kernel_variant=3, stats=True)
     assert c3.rays_traced == 60 * d.nlive_rays and d.nlive_rays == 883790
     assert 3.5e10 < c3.ray_steps < 4.1e10
     assert e3[257, 257, 257] == 0.0 and (e3[250:264, 250:264, 250:264] == 0).all()
@@ -527,12 +528,15 @@ def test_window_kernel_combines_and_is_parity_exact(api, oracle, inputs, torch_c
     bn, r, ne, te = inputs
     beams = [0, 7, 19, 23, 31, 38, 44, 52, 57, 59]
     tr = make_tracer(api, inputs, 56, beams=beams)
-    e, c = run(tr, torch_cuda, kernel_variant=3)
+    e, c = run(tr, torch_cuda, kernel_variant=3, stats=True)     # (cbet_params.window_stats: the counting instantiation)
     oe, osteps = oracle.trace(oracle.default_config(56, nbeams=len(beams)), bn[beams].copy(), r, ne, te,
                               nthreads=NCPU)
     assert c.ray_steps == osteps
     assert parity_err(e, oe) < PARITY_TOL
-    assert c.global_atomics < 0.6 * c.ray_steps          # the window really combines
+    e_plain, c_plain = run(tr, torch_cuda, kernel_variant=3)     # ... and the one that does not count: same rays, same grid
+    assert c_plain.ray_steps == osteps and c_plain.rays_traced == c.rays_traced and parity_err(e_plain, oe) < PARITY_TOL
+    assert 0 < c.global_atomics < 0.6 * c.ray_steps      # the window really combines
+    assert 64 * c.wave_steps >= c.ray_steps > 32 * c.wave_steps
     assert c.wave_steps_miss < 0.2 * c.wave_steps and c.lds_evictions < 0.05 * c.ray_steps
     tr.close()
 
@@ -556,7 +560,7 @@ def test_stress_512_properties(api, inputs, torch_cuda):
     tr = make_tracer(api, inputs, 512)
     d = tr.derived
     assert (d.nrays, d.nt) == (501264, 2048)
-    e3, c3 = run(tr, torch_cuda, kernel_variant=3)
+    e3, c3 = run(tr, torch_cuda, kernel_variant=3, stats=True)
     assert c3.rays_traced == 60 * d.nlive_rays
     assert 1.5e10 < c3.ray_steps < 2.0e10
     assert e3[257, 257, 257] == 0.0 and (e3[250:264, 250:264, 250:264] == 0).all()
@@ -629,7 +633,7 @@ def test_native_wide_index_grid_832(api, inputs, torch_cuda):
     tr = make_tracer(api, inputs, 832, beams=[0, 21, 40, 59])
     d = tr.derived
     assert 8 * tr.params.nx * tr.params.ny * tr.params.nz >= 2 ** 32
-    e3, c3 = run(tr, torch_cuda, kernel_variant=3)
+    e3, c3 = run(tr, torch_cuda, kernel_variant=3, stats=True)
     assert c3.rays_traced == 4 * d.nlive_rays and c3.ray_steps > 3e9
     s3, m3, z3 = float(e3.sum()), float(e3.max()), e3[417, 417, 417]
     del e3
