@@ -19,8 +19,11 @@ HEADERS = [os.path.join(CSRC, "cbet_device.h"), os.path.join(CSRC, "cbet_relocat
 
 # -ffp-contract=off: a ray's fp64 arithmetic must be the reference's operation sequence (no fused
 # multiply-add), see cbet_kernels.hip.  No -ffast-math: fp64 div/sqrt stay correctly rounded.
+# -structurizecfg-skip-uniform-regions: the trace kernel's step loop branches on wave-uniform conditions only (scalar masks);
+# structurised like divergent control flow, every such branch gets flow blocks whose phis cost the common path ~40 scalar
+# copies per step (two per loop-carried value).  Uniform regions are left as the source wrote them.
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared",
-         "-Wall", "-Wextra", "-Wno-unused-result"]
+         "-Wall", "-Wextra", "-Wno-unused-result", "-mllvm", "-structurizecfg-skip-uniform-regions=true"]
 
 
 def hipcc():

@@ -464,6 +464,17 @@ __device__ __forceinline__ double max_abs3(double a, double b, double c)
     return r;
 }
 
+// var = value through a move TIED to var's register: the new value lives where the old one did (see the window arm)
+__device__ __forceinline__ void commit(int &var, int value)
+{
+    asm volatile("s_mov_b32 %0, %1" : "+s"(var) : "s"(__builtin_amdgcn_readfirstlane(value)));   // (wave-uniform by construction)
+}
+__device__ __forceinline__ void commit(unsigned long long &var, unsigned long long value)
+{
+    asm volatile("s_mov_b64 %0, %1" : "+s"(var) : "s"(value));
+}
+__device__ __forceinline__ void commit_v(int &var, int value) { asm volatile("v_mov_b32 %0, %1" : "+v"(var) : "v"(value)); }
+
 // a * b + c on 24-bit operands (the compiler picked the quarter-rate v_mad_u64_u32 for one of the two).  b is a scalar
 // register: on gfx940 / gfx950 a vector instruction that reads an SGPR needs two wait states after a vector instruction
 // that wrote it (a v_readlane reloading it from a spill lane), a hazard the compiler tracks for its own instructions
@@ -496,8 +507,8 @@ constexpr double kFarJump = 1.4998;   // relocate_deep_interior's validity bound
 #define CBET_LANES(mask) __builtin_amdgcn_inverse_ballot_w64(mask)
 
 // Lane predicates of the step loop are kept as 64-bit masks in scalar registers and combined there explicitly: `live`
-// (the ray is still traced), `hbm` (its home is box B), `inbox_m` / `miss_m` (where its pending deposit belongs: an LDS
-// box / straight to HBM).  A per-lane copy of a predicate costs the compiler merges under the exec mask wherever it
+// (the ray is still traced), `hbm` (its home is box B), `miss_m` (its pending deposit goes straight to HBM instead of an
+// LDS box).  A per-lane copy of a predicate costs the compiler merges under the exec mask wherever it
 // crosses a branch (three scalar instructions each); a mask costs nothing until it is used (CBET_LANES).
 //
 // STATS: the window diagnostics (wave-steps, misses, box-B steps, planes retired, global atomics) are counted only by
@@ -547,7 +558,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
     double *const tileA = s_val, *const tileB = s_val + T::N;
     Origin oA{0, 0, 0}, oB{0, 0, 0};
     unsigned long long hbm = 0ull; // lanes whose deposits go to box B
-    bool b_active = false;         // wave-uniform
+    int b_active = 0;              // wave-uniform flag: box B holds lanes
     {
         const int src = ((live >> 27) & 1ull) ? 27 : (__ffsll((long long)live) - 1);
         for (int z = lane; z < NLDS; z += kWave) s_val[z] = 0.0;
@@ -557,8 +568,8 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         if (T::BRICK) oA.z &= ~7;
         __syncthreads();
     }
-    // wave-uniform: every live lane was held by a box after the last step and both boxes lie deep inside the grid
-    bool deep = false;
+    // wave-uniform flag: every live lane was held by a box after the last step and both boxes lie deep inside the grid
+    int deep = 0;
 #ifdef CBET_DIAG_CLOCKS
     // diagnostic build (never shipped): shader-clock cycles this wave spends in the record wait and in the window-shift
     // path, reported through the counter slots (see the end of the kernel)
@@ -617,9 +628,11 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
     double Fx0 = 0, Fx1 = 0, Fy0 = 0, Fy1 = 0, Fz0 = 0, Fz1 = 0;   // the step's six per-axis factors
     int X0 = 0, X1 = 0, Y0 = 0, Y1 = 0, Z0 = 0, Z1 = 0;            // the nodes the lane's pending sums belong to (haloed)
     double inc = 0.0;                        // :305-311 the energy the step deposits
-    unsigned long long inbox_m = 0ull;       // lanes whose pending deposit goes to LDS ...
-    int tile_off = 0;                        // ... into this tile (offset in doubles; per lane, 0 while box B is idle)
-    unsigned long long miss_m = 0ull;        // ... lanes whose pending deposit goes straight to HBM (outside both boxes)
+    // Where a live lane's pending deposit belongs: an LDS box -- the tile at tile_off (in doubles; per lane, 0 while box B
+    // is idle) -- unless the lane is in miss_m (outside both boxes after the last window pass): then straight to HBM.
+    // (A ray that ends hands its deposit over at once, so only live lanes ever hold one.)
+    int tile_off = 0;
+    unsigned long long miss_m = 0ull;
     int own_slot = 0, own_node = 0;          // CBET = 4: the ray's own node, in box A's component tiles / in the grid
     // Eight sums to the lane's eight nodes X0..Z1 in LDS.  slot = (x & XM) * XS + (y & YM) * YS + zr with the masks and
     // strides of the lane's tile (byte offsets throughout: 24-bit multiplies by the byte strides, one three-operand
@@ -660,7 +673,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
                 add(add3(x1, y1, zb(Z1, rb + sb)), w[7]);
             }
         };
-        if (!b_active) {   // scalar branch: everything goes to box A, compile-time masks and strides
+        if (b_active == 0) {   // scalar branch: everything goes to box A, compile-time masks and strides
             add8(T::XM, T::YM, T::ZM, T::XS, T::YS, 0, T::ROT ? 1 : 0);
         } else {
             const bool toB = tile_off != 0;
@@ -687,7 +700,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
     // crosses the loop edge: the six per-axis factors, the node indices, the increment, where it goes.  (Their gain
     // hooks leave no registers for the pending sums below: with them the energy-field pass spills and takes 33 ms
     // instead of 25.)
-    auto deposit_previous = [&]() {
+    auto deposit_step = [&](unsigned long long lds_m, unsigned long long hbm_m) {
         // 14 products instead of the reference's 20: ((Fz * inc) * Fy) * Fx for ((Fz * Fy) * Fx) * inc -- three roundings
         // either way, i.e. a deposit differs from the reference's by at most 2 ulp (the sum order of the atomics already
         // moves a cell's total by more: SURVEY 8(c)'s metric is 1e-9).  The ray's own state (position, velocity, energy,
@@ -704,11 +717,11 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         wgt[5] = zy01 * Fx1;
         wgt[6] = zy11 * Fx0;
         wgt[7] = zy11 * Fx1;
-        if (CBET_LANES(inbox_m)) lds_add8(wgt);
+        if (CBET_LANES(lds_m)) lds_add8(wgt);
         // window misses: eight atomics, younger than the record gather just issued -- counted for its wait
-        if (miss_m != 0ull) {
+        if (hbm_m != 0ull) {
             wc.pend += 8;
-            if (CBET_LANES(miss_m)) {
+            if (CBET_LANES(hbm_m)) {
                 hbm_add8(wgt);
                 ++wc.n_miss;
             }
@@ -716,22 +729,20 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         if (CBET == 4) {
             // Displacement components: the ray's own node only -- box A's tiles, or HBM for a lane of
             // box B / outside the boxes.
-            const bool inbox = CBET_LANES(inbox_m);
+            const bool inbox = CBET_LANES(lds_m);
             if (inbox && tile_off == 0) {
                 if (CBET_AUDIT(a, (unsigned)(own_slot + 2 * T::DT) < (unsigned)NLDS)) {
                     __hip_atomic_fetch_add(&s_val[own_slot], q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_fetch_add(&s_val[own_slot + T::DT], q2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_fetch_add(&s_val[own_slot + 2 * T::DT], q3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-            } else if (inbox || CBET_LANES(miss_m)) {
+            } else if (inbox || CBET_LANES(hbm_m)) {
                 global_add(a, &edep[a.comp_stride + own_node], q1);
                 global_add(a, &edep[2 * a.comp_stride + own_node], q2);
                 global_add(a, &edep[3 * a.comp_stride + own_node], q3);
                 wc.n_atomics += 3;
             }
         }
-        inbox_m = 0ull;
-        miss_m = 0ull;
     };
 
     // ---- deposits, the plain trace (ACC = true): summed in registers while the ray's eight nodes stay the same ----------
@@ -746,7 +757,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
     unsigned long long restart_m = 0ull;     // lanes whose sums went out in this step's flush and restart with its deposit
     bool p_odd = true;                       // wave-uniform: the nodes came from the rare (non-negative offset) branch
     auto accumulate = [&]() {
-        // 14 products instead of the reference's 20 (see deposit_previous).  S * 1 + w and S * 0 + w are exact forms of
+        // 14 products instead of the reference's 20 (see deposit_step).  S * 1 + w and S * 0 + w are exact forms of
         // "S + w" and "w": one fma each, written IN PLACE (left to the compiler it becomes v_fmac into the product's
         // register and eight 64-bit copies back at the loop edge)
         const double zi0 = Fz0 * inc, zi1 = Fz1 * inc;
@@ -762,20 +773,53 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         add(S[6], zy11 * Fx0);
         add(S[7], zy11 * Fx1);
     };
-    // changed_m: lanes whose nodes are about to change (or whose ray has ended)
-    auto flush_pending = [&](unsigned long long changed_m) {
-        const unsigned long long fl_m = changed_m & (inbox_m | miss_m);
-        if (fl_m != 0ull) {   // scalar branch (taken in 99 % of the wave-steps: some lane always moves on)
-            if (CBET_LANES(fl_m & inbox_m)) lds_add8(S);
-            // window misses: eight atomics, younger than the record gather just issued -- counted for its wait.  (Asked
-            // only when the last window pass left some lane outside both boxes: 1 % of the wave-steps.)
-            if (miss_m != 0ull) {
-                const unsigned long long out_m = fl_m & miss_m;
-                wc.pend += out_m != 0ull ? 8 : 0;
-                if (CBET_LANES(out_m)) hbm_add8(S);
-            }
+    // the pending sums of the lanes in lds_m go to their LDS box, those of the lanes in hbm_m straight to HBM
+    auto flush_sums = [&](unsigned long long lds_m, unsigned long long hbm_m) {
+        if (CBET_LANES(lds_m)) lds_add8(S);
+        // window misses: eight atomics, younger than the record gather just issued -- counted for its wait
+        if (hbm_m != 0ull) {
+            wc.pend += 8;
+            if (CBET_LANES(hbm_m)) hbm_add8(S);
         }
-        restart_m = fl_m;
+    };
+
+    // ---- the rest of a step: wait for the record, absorb, add the deposit to the pending sums, end rays -------------
+    auto step_tail = [&](int &tt) {
+    // ---- absorption (:305-311) ---------------------------------------------------------------------
+    await_record();   // the record gathered after the relocation: kappa now, the kicks at the top of the next step
+    if (absorb) {
+        inc = rec_kzk.y * s.uray;
+        s.uray -= inc;
+    } else {
+        inc = s.uray;
+    }
+    if (CBET >= 2) inc = q0;   // field passes deposit energy x path length
+    if constexpr (ACC) accumulate();   // the step's deposit joins the lane's pending sums
+    // ---- termination (:351-356) --------------------------------------------------------------------
+    // The six exit planes are compared only when the wave is not deep inside the grid: a lane held by a deep
+    // box is more than two cells from every face, far beyond the half cell of :352-354.  Ballots of plain
+    // compares over all lanes, masked with `live` on the scalar unit.
+    unsigned long long died = CBET_BALLOT(s.uray <= s.ustop);
+    if (slow || deep == 0) {   // scalar branch
+        const double *b = a.bounds;  // {xlo, xhi, ylo, yhi, zlo, zhi}
+        died |= CBET_BALLOT(s.px < b[0]) | CBET_BALLOT(s.px > b[1]) | CBET_BALLOT(s.py < b[2]) |
+                CBET_BALLOT(s.py > b[3]) | CBET_BALLOT(s.pz < b[4]) | CBET_BALLOT(s.pz > b[5]);
+    }
+    died &= live;
+    if (died != 0ull) {   // scalar branch: some ray ended in this step, its tt + 1-th
+        asm volatile("");
+        commit(tot_steps, tot_steps + __popcll(died) * (tt + 1));
+        // its deposit goes where the window pass of this step put it, now (the boxes stand for exactly these nodes)
+        if constexpr (ACC) flush_sums(died & ~miss_m, died & miss_m);
+        else deposit_step(died & ~miss_m, died & miss_m);
+        commit(live, live & ~died);
+        commit(hbm, hbm & live);
+        commit(miss_m, miss_m & live);
+        // (every ray has ended: the loop ends through its one exit, the step count -- a second exit costs the common path
+        // the copies and flags of the compiler's exit unification)
+        if (live == 0ull) commit(tt, a.nt - 1);
+    }
+    __builtin_amdgcn_wave_barrier();
     };
 
     for (int tt = 0; tt < a.nt; ++tt) {                        // :207  (live != 0 here: checked where lanes end)
@@ -799,7 +843,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
                    upz = g0z >= kNearTol, dnz = g0z < kNearTol - 1.0;
         // wave-uniform: this step runs the general (face-aware) forms.  One compare of the largest |g| (a NaN -- which
         // moves no cell in either form -- is ignored by the maximum)
-        slow = !deep || (CBET_BALLOT(!(max_abs3(g0x, g0y, g0z) < kFarJump)) & live) != 0ull;
+        slow = deep == 0 || (CBET_BALLOT(!(max_abs3(g0x, g0y, g0z) < kFarJump)) & live) != 0ull;
         // ---- relocate, gather -------------------------------------------------------------------
         // The deep-interior form updates the cell IN PLACE; the rare general form takes the update back first (kept as
         // copies for it, the old cell costs the common path three moves).
@@ -827,7 +871,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         fcx = (double)s.ci;
         fcy = (double)s.cj;
         fcz = (double)s.ck;
-        if constexpr (!ACC) deposit_previous();   // the previous step's deposit, in the shadow of the gather
+        if constexpr (!ACC) deposit_step(live & ~miss_m, miss_m);   // the previous step's deposit, in the shadow of the gather
         // ---- weights (:319-339) -----------------------------------------------------------------
         // Each weight is (Fz * Fy) * Fx * inc with F = (1-d) for the ray's own node along that axis and F = d
         // for the neighbour on the `sign` side (:329-336).  The neighbour lies on the side of the offset's sign
@@ -848,7 +892,12 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         // the pending sums leave for the nodes they belong to before those are replaced: a lane whose cell changed (the
         // low corner is a function of the cell while the offsets are negative), every lane around the rare branch
         if constexpr (ACC) {
-            flush_pending((all_negative && !p_odd) ? (~live | moved_m) : ~0ull);
+            const unsigned long long fl_m = (all_negative && !p_odd) ? (live & moved_m) : live;
+            if (fl_m != 0ull) {   // scalar branch (taken in 99 % of the wave-steps: some lane always moves on)
+                if (miss_m == 0ull) flush_sums(fl_m, 0ull);      // (the usual case without the mask arithmetic)
+                else flush_sums(fl_m & ~miss_m, fl_m & miss_m);
+            }
+            restart_m = fl_m;
             p_odd = !all_negative;
         }
         {
@@ -932,14 +981,13 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         }
         // ---- windows ----------------------------------------------------------------------------------
         // Common case, decided with three compares: every live lane's eight target nodes lie inside its home box
-        // -- nothing has to move: the lanes deposit into LDS (inbox_m = live), box A's while box B is idle (tile_off = 0:
-        // every path that retires B leaves it so), and none lies outside both boxes.  (The boxes follow on demand: the
-        // step in which a lane leaves is the step in which its box is shifted, before anything is deposited.)
-        inbox_m = live;
+        // -- nothing has to move: the lanes deposit into LDS, box A's while box B is idle (tile_off = 0: every path that
+        // retires B leaves it so), and none lies outside both boxes.  (The boxes follow on demand: the step in which a
+        // lane leaves is the step in which its box is shifted, before anything is deposited.)
         const unsigned long long memA = live & ~hbm;
         unsigned long long out_core = memA & ~(CBET_BALLOT((unsigned)rx <= (unsigned)T::SX) & CBET_BALLOT((unsigned)ry <= (unsigned)T::SY) &
                                                CBET_BALLOT((unsigned)rz <= (unsigned)T::SZ));
-        if (b_active) {   // scalar branch
+        if (b_active != 0) {   // scalar branch
             asm volatile("");   // (a real branch: if-converted, its assignments cost the common path two selects)
             if constexpr (STATS) wc.slabs_bsteps += 1u;
             const int abx = oA.x - oB.x, aby = oA.y - oB.y, abz = oA.z - oB.z;
@@ -948,61 +996,76 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
                                 CBET_BALLOT((unsigned)(rz + abz) <= (unsigned)TB::SZ));
             tile_off = CBET_LANES(hbm) ? T::N : 0;
         }
+        // (lanes the last window pass left outside both boxes send the wave through the general arm again, which clears or
+        // renews their mark: 1 % of the wave-steps)
+        out_core |= miss_m;
         if (out_core != 0ull) {
 #ifdef CBET_DIAG_CLOCKS
             unsigned long long dg_t0;
             asm volatile("s_memtime %0" : "=&s"(dg_t0) : : "memory");
 #endif
+            // The wave-uniform state this arm changes -- box origins, masks, flags -- is worked on in COPIES and written back
+            // at the end through commit(): an assembly move TIED to the variable's register, so that the value the arm leaves
+            // and the one the common path carries meet in one register (left to the compiler every such variable costs the
+            // common path two scalar copies per step, where the arms join and at the loop's back edge).
             const bool alive = CBET_LANES(live);
-            const int lx = rx + oA.x, ly = ry + oA.y, lz = rz + oA.z;   // (before box A moves)
+            int lx = rx + oA.x, ly = ry + oA.y, lz = rz + oA.z;   // (before box A moves)
+            asm volatile("" : "+v"(lx), "+v"(ly), "+v"(lz));      // (formed here: the old origin is not kept for them)
+            Origin nA = oA, nB = oB;
+            unsigned long long n_hbm = hbm, n_miss = 0ull;
+            int n_bact = b_active, n_deep, n_toff = tile_off;
             // box A follows the lanes whose home it is
-            follow_box<T, NC>(a, tileA, oA, memA, lx, ly, lz, lane, edep, sXh, sYh, wc, NSLOT, a.comp_stride);
+            follow_box<T, NC>(a, tileA, nA, memA, lx, ly, lz, lane, edep, sXh, sYh, wc, NSLOT, a.comp_stride);
             const unsigned long long lost_mask =
-                memA & ~(CBET_BALLOT((unsigned)(lx - oA.x) <= (unsigned)T::SX) & CBET_BALLOT((unsigned)(ly - oA.y) <= (unsigned)T::SY) &
-                         CBET_BALLOT((unsigned)(lz - oA.z) <= (unsigned)T::SZ));
-            if (lost_mask == 0ull && !b_active) {
-                // the usual outcome: A moved and holds every live lane again (inbox_m = live, tile_off = 0 stand)
-                deep = box_deep_inside<T>(oA, nx, ny, nz);
+                memA & ~(CBET_BALLOT((unsigned)(lx - nA.x) <= (unsigned)T::SX) & CBET_BALLOT((unsigned)(ly - nA.y) <= (unsigned)T::SY) &
+                         CBET_BALLOT((unsigned)(lz - nA.z) <= (unsigned)T::SZ));
+            if (lost_mask == 0ull && n_bact == 0) {
+                // the usual outcome: A moved and holds every live lane again (tile_off = 0 stands, nobody outside)
+                n_deep = box_deep_inside<T>(nA, nx, ny, nz) ? 1 : 0;
             } else {
                 bool homeB = CBET_LANES(hbm);
-                const bool inA = alive && holds<T>(oA, lx, ly, lz);
+                const bool inA = alive && holds<T>(nA, lx, ly, lz);
                 const bool lost = alive && !homeB && !inA;
                 // lanes that fell out of A look for a home in B, which follows its own lanes only (letting it chase the
                 // lost ones as well was measured: more misses, 0.63 % against 0.48 % of the ray-steps); an idle B is
                 // re-created around the first lost lane
-                if (b_active) {  // scalar branch
-                    follow_box<TB, 1>(a, tileB, oB, hbm, lx, ly, lz, lane, edep, sXh, sYh, wc, 0, 0);
+                if (n_bact != 0) {  // scalar branch
+                    follow_box<TB, 1>(a, tileB, nB, hbm, lx, ly, lz, lane, edep, sXh, sYh, wc, 0, 0);
                 } else if (lost_mask != 0ull) {
                     const int src = __ffsll((long long)lost_mask) - 1;
                     const int sx = __builtin_amdgcn_readlane(lx, src), sy = __builtin_amdgcn_readlane(ly, src),
                               sz = __builtin_amdgcn_readlane(lz, src);
-                    oB.x = sx - (TB::WX / 2 - 1);
-                    oB.y = sy - (TB::WY / 2 - 1);
-                    oB.z = sz - TB::SZ / 2;
-                    b_active = true;  // its tile is all zero: zeroed at start and flushed whenever it empties
+                    nB.x = sx - (TB::WX / 2 - 1);
+                    nB.y = sy - (TB::WY / 2 - 1);
+                    nB.z = sz - TB::SZ / 2;
+                    n_bact = 1;  // its tile is all zero: zeroed at start and flushed whenever it empties
                 }
-                const bool inB = alive && holds<TB>(oB, lx, ly, lz);
+                const bool inB = alive && holds<TB>(nB, lx, ly, lz);
                 homeB = homeB || (lost && inB);
                 // a B lane that drifted out of B but back into A goes home
                 if (alive && homeB && !inB && inA) homeB = false;
-                hbm = CBET_BALLOT(alive && homeB);
-                if (hbm == 0ull) {
+                n_hbm = CBET_BALLOT(alive && homeB);
+                if (n_hbm == 0ull) {
                     __builtin_amdgcn_wave_barrier();
-                    flush_box<TB, 1>(a, tileB, oB, lane, edep, sXh, sYh, wc, 0, 0);
-                    b_active = false;
+                    flush_box<TB, 1>(a, tileB, nB, lane, edep, sXh, sYh, wc, 0, 0);
+                    n_bact = 0;
                 }
                 __builtin_amdgcn_wave_barrier();
                 const bool useB = alive && homeB && inB;
-                tile_off = useB ? T::N : 0;
-                inbox_m = CBET_BALLOT(useB || (alive && !homeB && inA));
-                const bool any_missed = (live & ~inbox_m) != 0ull;
+                n_toff = useB ? T::N : 0;
+                n_miss = live & ~CBET_BALLOT(useB || (alive && !homeB && inA));
                 if constexpr (STATS) {
-                    if (any_missed) wc.steps_miss += 1u;
-                    if (ACC && alive && !CBET_LANES(inbox_m)) ++wc.n_miss;   // ray-steps whose deposit is bound for HBM (ACC: counted
-                                                                            // here, the only place a lane can come to lie outside both boxes)
+                    if (n_miss != 0ull) wc.steps_miss += 1u;
+                    if (ACC && CBET_LANES(n_miss)) ++wc.n_miss;   // ray-steps whose deposit is bound for HBM (ACC: counted here,
+                                                                 // the only place a lane can come to lie outside both boxes)
                 }
-                deep = !any_missed && box_deep_inside<T>(oA, nx, ny, nz) && (!b_active || box_deep_inside<TB>(oB, nx, ny, nz));
+                n_deep = (n_miss == 0ull && box_deep_inside<T>(nA, nx, ny, nz) && (n_bact == 0 || box_deep_inside<TB>(nB, nx, ny, nz))) ? 1 : 0;
             }
+            commit(oA.x, nA.x); commit(oA.y, nA.y); commit(oA.z, nA.z);
+            commit(oB.x, nB.x); commit(oB.y, nB.y); commit(oB.z, nB.z);
+            commit(hbm, n_hbm); commit(miss_m, n_miss);
+            commit(b_active, n_bact); commit(deep, n_deep);
+            commit_v(tile_off, n_toff);
             // (the write-back paths keep the count in a vector register; the common path's stays scalar this way)
             wc.pend = __builtin_amdgcn_readfirstlane(wc.pend);
 #ifdef CBET_DIAG_CLOCKS
@@ -1013,49 +1076,20 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
                 dg_nshift += 1;
             }
 #endif
-            miss_m = live & ~inbox_m;
-        } else {
-            if (!deep) deep = box_deep_inside<T>(oA, nx, ny, nz) && (!b_active || box_deep_inside<TB>(oB, nx, ny, nz));
-            miss_m = 0ull;
+        } else if (deep == 0) {
+            const int d = (box_deep_inside<T>(oA, nx, ny, nz) && (b_active == 0 || box_deep_inside<TB>(oB, nx, ny, nz))) ? 1 : 0;
+            commit(deep, d);
         }
-        // ---- absorption (:305-311) ---------------------------------------------------------------------
-        await_record();   // the record gathered after the relocation: kappa now, the kicks at the top of the next step
-        if (absorb) {
-            inc = rec_kzk.y * s.uray;
-            s.uray -= inc;
-        } else {
-            inc = s.uray;
-        }
-        if (CBET >= 2) inc = q0;   // field passes deposit energy x path length
-        if constexpr (ACC) accumulate();   // the step's deposit joins the lane's pending sums
-        // ---- termination (:351-356) --------------------------------------------------------------------
-        // The six exit planes are compared only when the wave is not deep inside the grid: a lane held by a deep
-        // box is more than two cells from every face, far beyond the half cell of :352-354.  Ballots of plain
-        // compares over all lanes, masked with `live` on the scalar unit.
-        unsigned long long died = CBET_BALLOT(s.uray <= s.ustop);
-        if (slow || !deep) {   // scalar branch
-            const double *b = a.bounds;  // {xlo, xhi, ylo, yhi, zlo, zhi}
-            died |= CBET_BALLOT(s.px < b[0]) | CBET_BALLOT(s.px > b[1]) | CBET_BALLOT(s.py < b[2]) |
-                    CBET_BALLOT(s.py > b[3]) | CBET_BALLOT(s.pz < b[4]) | CBET_BALLOT(s.pz > b[5]);
-        }
-        died &= live;
-        if (died != 0ull) {   // scalar branch: some ray ended in this step, its tt + 1-th
-            asm volatile("");
-            tot_steps += __popcll(died) * (tt + 1);
-            live &= ~died;
-            hbm &= live;
-            if (live == 0ull) break;
-        }
-        __builtin_amdgcn_wave_barrier();
+        step_tail(tt);
     }
     tot_steps += __popcll(live) * a.nt;      // rays that ran out of steps (:207)
 
     // every lane's pending sums (or the last step's deposit), then whatever is still in LDS
-    if constexpr (ACC) flush_pending(~0ull);
-    else deposit_previous();
+    if constexpr (ACC) flush_sums(live & ~miss_m, live & miss_m);
+    else deposit_step(live & ~miss_m, live & miss_m);
     __syncthreads();
     flush_box<T, NC>(a, tileA, oA, lane, edep, sXh, sYh, wc, NSLOT, a.comp_stride);
-    if (b_active) flush_box<TB, 1>(a, tileB, oB, lane, edep, sXh, sYh, wc, 0, 0);
+    if (b_active != 0) flush_box<TB, 1>(a, tileB, oB, lane, edep, sXh, sYh, wc, 0, 0);
 
     if (CBET && a.beam_gain) {  // one fp64 atomic per wave
         double t = gained;
