@@ -235,16 +235,26 @@ __device__ __forceinline__ void retire_zbrick(const TraceArgs &a, double *tile, 
     const int ty = lane >> 3, kz = lane & 7;
     const int tz = (zb + kz) & T::ZM;
     const int base_node = abs_in<T::YM>(o.y, ty) * sYh + zb + kz;
+    // all reads of a round first, one trip through the LDS queue per round (a read behind its own wait costs a trip each:
+    // eight in a row were 2 % of the pass)
+    constexpr int ROUND = 4;
 #pragma unroll
-    for (int tx = 0; tx < T::WX; ++tx) {
-        const int slot = tx * T::XS + ty * T::YS + T::zr(tx, ty, tz);
-        if (!CBET_AUDIT(a, (unsigned)slot < (unsigned)T::N)) continue;
-        const double v = tile[slot];
-        wc.pend += (CBET_BALLOT(v != 0.0) != 0ull) ? 1 : 0;
-        if (v != 0.0) {
-            tile[slot] = 0.0;
-            ++wc.n_atomics;
-            global_add(a, &edep[abs_in<T::XM>(o.x, tx) * sXh + base_node], v);
+    for (int t0 = 0; t0 < T::WX; t0 += ROUND) {
+        double v[ROUND];
+        int slot[ROUND];
+#pragma unroll
+        for (int q = 0; q < ROUND; ++q) {
+            slot[q] = (t0 + q) * T::XS + ty * T::YS + T::zr(t0 + q, ty, tz);
+            v[q] = CBET_AUDIT(a, (unsigned)slot[q] < (unsigned)T::N) ? tile[slot[q]] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < ROUND; ++q) {
+            wc.pend += (CBET_BALLOT(v[q] != 0.0) != 0ull) ? 1 : 0;
+            if (v[q] != 0.0) {
+                tile[slot[q]] = 0.0;
+                ++wc.n_atomics;
+                global_add(a, &edep[abs_in<T::XM>(o.x, t0 + q) * sXh + base_node], v[q]);
+            }
         }
     }
 }
@@ -267,19 +277,23 @@ __device__ __forceinline__ void flush_box(const TraceArgs &a, double *tile, cons
 // shift costs mostly its fixed part -- the decisions and a round trip through the LDS queue.
 __device__ __forceinline__ int follow_plane_axis(int r, unsigned long long mm, int S)
 {
-    if ((__builtin_amdgcn_ballot_w64((unsigned)(r - 1) >= (unsigned)(S - 1)) & mm) == 0ull) return 0;
-    const bool below = (__builtin_amdgcn_ballot_w64(r < 0) & mm) != 0ull, at_lo = (__builtin_amdgcn_ballot_w64(r <= 0) & mm) != 0ull,
-               near_lo = (__builtin_amdgcn_ballot_w64(r <= 1) & mm) != 0ull;
-    const bool above = (__builtin_amdgcn_ballot_w64(r > S) & mm) != 0ull, at_hi = (__builtin_amdgcn_ballot_w64(r >= S) & mm) != 0ull,
-               near_hi = (__builtin_amdgcn_ballot_w64(r >= S - 1) & mm) != 0ull;
-    const bool want_down = below || (at_lo && !near_hi), want_up = above || (at_hi && !near_lo);
-    int d = (want_down && !at_hi) ? -1 : ((want_up && !at_lo) ? 1 : 0);
-    if (S >= 6 && d != 0) {
-        const bool lo2 = (__builtin_amdgcn_ballot_w64(r <= 2) & mm) != 0ull, hi2 = (__builtin_amdgcn_ballot_w64(r >= S - 2) & mm) != 0ull;
-        if (d == 1 && !lo2) d = 2;      // (three planes at once, where the bundle is narrow enough, measured no better)
-        if (d == -1 && !hi2) d = -2;
+    // The rule: with below / at_lo / near_lo = some member at r < 0 / <= 0 / <= 1 and above / at_hi / near_hi = some member
+    // at r > S / >= S / >= S - 1, shift down iff (below or (at_lo and not near_hi)) and not at_hi, up iff (above or (at_hi
+    // and not near_lo)) and not at_lo; by two planes when no member lies within two planes of the far edge.  Evaluated as
+    // a decision tree -- four ballots on the usual path (a member on one edge, nobody near the other) instead of the
+    // eight thresholds.
+    const unsigned long long edge = __builtin_amdgcn_ballot_w64((unsigned)(r - 1) >= (unsigned)(S - 1)) & mm;   // r <= 0 or r >= S
+    if (edge == 0ull) return 0;
+    const unsigned long long hi = __builtin_amdgcn_ballot_w64(r >= S) & edge;     // at_hi (a member above the box included)
+    const bool at_hi = hi != 0ull, at_lo = hi != edge;                            // (the edge lanes that are not high are low)
+    if (at_hi == at_lo) return 0;                                                 // members on both edges: stay
+    if (at_hi) {   // not at_lo, hence not below: up iff above or not near_lo
+        if ((__builtin_amdgcn_ballot_w64(r <= 1) & mm) != 0ull) return (__builtin_amdgcn_ballot_w64(r > S) & mm) != 0ull ? 1 : 0;
+        return (S >= 6 && (__builtin_amdgcn_ballot_w64(r <= 2) & mm) == 0ull) ? 2 : 1;   // (three planes at once, where the bundle is narrow enough, measured no better)
     }
-    return d;
+    // at_lo only, hence not above: down iff below or not near_hi
+    if ((__builtin_amdgcn_ballot_w64(r >= S - 1) & mm) != 0ull) return (__builtin_amdgcn_ballot_w64(r < 0) & mm) != 0ull ? -1 : 0;
+    return (S >= 6 && (__builtin_amdgcn_ballot_w64(r >= S - 2) & mm) == 0ull) ? -2 : -1;
 }
 
 // ... and for z followed by aligned bricks (WZ = 16): the lane's two z nodes are r, r + 1 in [0, 16); shift by a
@@ -359,8 +373,10 @@ __device__ __forceinline__ bool holds(const Origin &o, int lx, int ly, int lz)
 template <class T>
 __device__ __forceinline__ bool box_deep_inside(const Origin &o, int nx, int ny, int nz)
 {
-    return o.x - 1 >= kRelocateDeep && o.x + T::SX <= nx - 3 && o.y - 1 >= kRelocateDeep && o.y + T::SY <= ny - 3 &&
-           o.z - 1 >= kRelocateDeep && o.z + T::SZ <= nz - 3;
+    // six differences that must all be >= 0: the OR of their sign bits in one compare (straight-line scalar code)
+    const int lo = kRelocateDeep + 1;
+    const int t = (o.x - lo) | (nx - 3 - T::SX - o.x) | (o.y - lo) | (ny - 3 - T::SY - o.y) | (o.z - lo) | (nz - 3 - T::SZ - o.z);
+    return t >= 0;
 }
 
 // ---------------------------------------------------------------------------------------------
