@@ -20,11 +20,16 @@ for nx, ny, nz, rpz, beams in [(64, 64, 64, 4, list(range(60))), (33, 20, 27, 3,
     p = api.default_params(nx, nbeams=len(beams), rays_per_zone=rpz)
     p.ny, p.nz = ny, nz
     tr = RayTracer(p, r, ne, te, beam_norm=np.ascontiguousarray(bn[beams]))
-    e = tr.new_grid()
-    tr.launch(e)
-    torch.cuda.synchronize()
-    v = api.debug_bounds_violations(reset=True)
-    print("audit %dx%dx%d rpz %d beams %d: %d out-of-range accesses attempted, edep_sum %.10e" % (nx, ny, nz, rpz, len(beams), v, float(e.sum().item())))
-    total += v
+    # dense rows (the reference's layout), rows padded to whole 64-byte lines (what every timed run uses: SweepPipeline) and an
+    # odd pitch: the write-back paths address the grid through its strides, and a variant wrong only with a pitch must not
+    # pass here and be timed un-audited
+    for pitch in (None, True, nz + 2 + 5):
+        e = tr.new_grid(zpitch=pitch) if pitch else tr.new_grid()
+        tr.launch(e, stats=True)
+        torch.cuda.synchronize()
+        v = api.debug_bounds_violations(reset=True)
+        print("audit %dx%dx%d rpz %d beams %d row pitch %d: %d out-of-range accesses attempted, edep_sum %.10e" % (
+            nx, ny, nz, rpz, len(beams), e.shape[2], v, float(e.sum().item())))
+        total += v
     tr.close()
 sys.exit(1 if total else 0)
