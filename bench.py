@@ -367,6 +367,9 @@ def main():
                      os.O_WRONLY | os.O_CREAT | os.O_APPEND, 0o644)
         os.dup2(fd, 2)
         os.close(fd)
+        if os.environ.get("CBET_BENCH_TEST_HANG"):     # tests/test_bench_cli.py: a rank that never comes back
+            print("rank %s: hanging on request (CBET_BENCH_TEST_HANG)" % os.environ["RANK"], file=sys.stderr, flush=True)
+            time.sleep(3600)
 
     import torch
     import torch.distributed as dist

@@ -229,14 +229,15 @@ __device__ __forceinline__ double phi_det(double x)
 // agree to the last bit or two, and the kernel is held to the checker at 1e-9.
 __device__ __forceinline__ double phi_small(double x)
 {
+    // (fused multiply-adds: 7 operations for 14; the checker's unfused Horner form differs in the last bit or two)
     double p = 1.0 / 40320.0;
-    p = p * x + 1.0 / 5040.0;
-    p = p * x + 1.0 / 720.0;
-    p = p * x + 1.0 / 120.0;
-    p = p * x + 1.0 / 24.0;
-    p = p * x + 1.0 / 6.0;
-    p = p * x + 0.5;
-    p = p * x + 1.0;
+    p = __builtin_fma(p, x, 1.0 / 5040.0);
+    p = __builtin_fma(p, x, 1.0 / 720.0);
+    p = __builtin_fma(p, x, 1.0 / 120.0);
+    p = __builtin_fma(p, x, 1.0 / 24.0);
+    p = __builtin_fma(p, x, 1.0 / 6.0);
+    p = __builtin_fma(p, x, 0.5);
+    p = __builtin_fma(p, x, 1.0);
     return p;
 }
 

@@ -28,6 +28,10 @@ def test_two_rank_bench_rehearsal():
     assert out["config"]["ray_steps_per_pass"] == 30712072                      # SURVEY.md 8(c), 64^3: both ranks' shares
     assert out["config"]["edep_sum"] == pytest.approx(6.1070952143e17, rel=1e-9)   # the slabs of the last pass, all ranks
     assert out["value"] > 0 and out["roofline"]["kernel_ms"] > 0
+    # who was in the group: both ranks' devices as they report them; ranks sharing a device over gloo = a rehearsal, flagged
+    rk = out["ranks"]
+    assert rk["process_group_ranks"] == 2 and len(rk["devices"]) == 2 and rk["rehearsal"] is True
+    assert rk["rccl_ranks"] == 0 and rk["distinct_devices"] == 1
 
 
 def test_two_rank_line_carries_a_roofline():
