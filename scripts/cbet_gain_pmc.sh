@@ -28,7 +28,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        name = "k_gain_field_sym" if "k_gain_field_sym" in k else ("k_trace_window<16,0,2> energy-field pass" if "k_trace_windowILi16ELb0ELi2" in k or "k_trace_window<16, false, 2" in k else None)
+        name = "k_gain_field_sym" if "k_gain_field_sym" in k else ("k_trace_window<16,0,2> energy-field pass" if "k_trace_windowILi16ELb0ELi2" in k or "k_trace_window<16, false, 2" in k else
+                                                                  ("k_trace_window<8,0,4> four-component field pass" if "k_trace_window<8, false, 4" in k else None))
         if name:
             agg[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
 with open(out + "/summary.txt", "w") as fo:

@@ -102,6 +102,21 @@ for c in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS
           "SQ_ACTIVE_INST_LDS"):
     if c in means:
         entry[c + "_per_launch"] = means[c][0]
+# the vector instructions by class (their own --pmc pass): bench.py weights them with the SIMD cycles scripts/ubench/valu_rate.hip
+# measured per class and reports roofline.valu_busy_frac
+for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU_CVT",
+          "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_BRANCH", "GRBM_GUI_ACTIVE"):
+    if c in means:
+        entry[c + "_per_launch"] = means[c][0]
+# the clock the chip held under this kernel: GRBM_GUI_ACTIVE counts busy cycles on each of the 8 XCDs; kernel time = the rocprofv3
+# kernel-trace average of the same command (kernel_stats.csv)
+ks = os.path.join(dst, "kernel_stats.csv")
+if "GRBM_GUI_ACTIVE" in means and os.path.exists(ks):
+    for r in csv.DictReader(open(ks)):
+        if "k_trace_window" in r["Name"] and ", true>(" not in r["Name"]:
+            entry["kernel_ns_rocprof_avg"] = float(r["AverageNs"])
+            entry["gpu_clock_hz_under_load"] = means["GRBM_GUI_ACTIVE"][0] / 8.0 / (float(r["AverageNs"]) * 1e-9)
+            break
 entry["shard_count"] = 1
 entries = [entry]
 # the same counter passes for ONE rank's share of a K-rank run, profiled on one GPU (bench.py --shard-of K, the middle
