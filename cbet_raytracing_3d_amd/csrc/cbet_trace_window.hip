@@ -320,7 +320,7 @@ __device__ __forceinline__ bool follow_box(const TraceArgs &a, double *tile, Ori
         const int first = d < 0 ? hi : lo, step = d < 0 ? -1 : 1, n = d < 0 ? -d : d;
         if constexpr (NC == 1) {
             if (n == 2) retire_planes<T, AX, 2>(a, tile, o, first, step, lane, edep, sXh, sYh, wc);
-            else retire_plane<T, AX, NC>(a, tile, o, first, lane, edep, sXh, sYh, wc, coff, gstride);
+            else retire_planes<T, AX, 1>(a, tile, o, first, step, lane, edep, sXh, sYh, wc);   // (both reads of the plane first: one trip through the LDS queue)
         } else {
             for (int q = 0; q < n; ++q) retire_plane<T, AX, NC>(a, tile, o, first + q * step, lane, edep, sXh, sYh, wc, coff, gstride);
         }
@@ -543,6 +543,9 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
     constexpr bool IDX64 = GENERIC;
     constexpr int NC = (CBET == 4) ? 4 : 1;
     constexpr bool ACC = (CBET == 0);   // deposits summed in registers until the ray's nodes change (see `accumulate`)
+    // ... and the addition itself runs in the NEXT step's gather shadow (the factors and the increment cross the loop edge):
+    // 23 vector instructions off the chain wait -> absorb -> move -> relocate -> gather (13.09 against 13.17 ms)
+    constexpr bool PIPE = ACC;
     constexpr int NSLOT = T::N + TB::N;                   // box A, box B
     constexpr int NLDS = NSLOT + (NC - 1) * T::DT;        // + components 1.. of box A (field pass)
     __shared__ double s_val[NLDS];
@@ -810,7 +813,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         inc = s.uray;
     }
     if (CBET >= 2) inc = q0;   // field passes deposit energy x path length
-    if constexpr (ACC) accumulate();   // the step's deposit joins the lane's pending sums
+    if constexpr (ACC && !PIPE) accumulate();   // the step's deposit joins the lane's pending sums
     // ---- termination (:351-356) --------------------------------------------------------------------
     // The six exit planes are compared only when the wave is not deep inside the grid: a lane held by a deep
     // box is more than two cells from every face, far beyond the half cell of :352-354.  Ballots of plain
@@ -826,6 +829,13 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         asm volatile("");
         commit(tot_steps, tot_steps + __popcll(died) * (tt + 1));
         // its deposit goes where the window pass of this step put it, now (the boxes stand for exactly these nodes)
+        if constexpr (PIPE) {
+            // (the step's deposit has not joined the sums yet: it does now, for every lane, and the next step's addition
+            // becomes S * 1 + 0 for the lanes that go on)
+            accumulate();
+            asm volatile("v_mov_b64 %0, 0" : "+v"(inc));
+            commit(restart_m, 0ull);
+        }
         if constexpr (ACC) flush_sums(died & ~miss_m, died & miss_m);
         else deposit_step(died & ~miss_m, died & miss_m);
         commit(live, live & ~died);
@@ -888,6 +898,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
         fcy = (double)s.cj;
         fcz = (double)s.ck;
         if constexpr (!ACC) deposit_step(live & ~miss_m, miss_m);   // the previous step's deposit, in the shadow of the gather
+        if constexpr (PIPE) accumulate();                           // ... or its addition to the pending sums
         // ---- weights (:319-339) -----------------------------------------------------------------
         // Each weight is (Fz * Fy) * Fx * inc with F = (1-d) for the ray's own node along that axis and F = d
         // for the neighbour on the `sign` side (:329-336).  The neighbour lies on the side of the offset's sign
@@ -1106,6 +1117,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
     tot_steps += __popcll(live) * a.nt;      // rays that ran out of steps (:207)
 
     // every lane's pending sums (or the last step's deposit), then whatever is still in LDS
+    if constexpr (PIPE) accumulate();     // (the last step's deposit of the rays that ran out of steps)
     if constexpr (ACC) flush_sums(live & ~miss_m, live & miss_m);
     else deposit_step(live & ~miss_m, live & miss_m);
     __syncthreads();

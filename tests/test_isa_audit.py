@@ -128,7 +128,11 @@ def test_resources_of_the_headline_instance(listing):
     # ... except the eight the source asks for by name: the pending sums, S = fma(S, k, w) with k = 1.0 or 0.0 (exact
     # forms of S + w and w), all with the same multiplier register
     # (v_fma_f64 S, S, k, w: written in place from inline assembly)
-    assert len(fused) == 8 and all(f[0] == "v_fma_f64" and f[1] == f[2] for f in fused) and len({f[3] for f in fused}) == 1, fused
+    # ... once in the gather's shadow (the previous step's deposit) and once more where a ray ends (its last deposit joins the
+    # sums before they are handed over): groups of eight
+    assert len(fused) in (8, 16) and all(f[0] == "v_fma_f64" and f[1] == f[2] for f in fused), fused
+    for g in range(0, len(fused), 8):
+        assert len({f[3] for f in fused[g:g + 8]}) == 1, fused[g:g + 8]
 
 
 # ---- gfx940 / gfx950 data hazards the compiler does not track into inline assembly ---------------------------------
