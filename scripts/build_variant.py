@@ -33,9 +33,31 @@ def main():
     os.makedirs(out_dir, exist_ok=True)
     with tempfile.TemporaryDirectory() as tmp:
         pkg = os.path.join(ROOT, "cbet_raytracing_3d_amd")
-        shutil.copytree(pkg, os.path.join(tmp, "cbet_raytracing_3d_amd"), ignore=shutil.ignore_patterns("lib", "__pycache__", "data"))
-        shutil.copytree(os.path.join(ROOT, "include"), os.path.join(tmp, "include"))
+
+        def today():
+            shutil.copytree(pkg, os.path.join(tmp, "cbet_raytracing_3d_amd"), ignore=shutil.ignore_patterns("lib", "__pycache__", "data"))
+            shutil.copytree(os.path.join(ROOT, "include"), os.path.join(tmp, "include"))
+
+        today()
         if os.path.exists(patch_path):
+            # A patch names the commit it was cut against ("# Base: <sha>").  The kernel moves on; when the patch no longer
+            # applies to today's tree the variant is built from `git archive <base>` of that commit instead, so that every
+            # recorded experiment stays rebuildable as scripts/variants/README.md promises (with today's compiler flags).
+            clean = subprocess.run(["patch", "-p1", "-s", "--dry-run", "-F0", "-i", patch_path], cwd=tmp, capture_output=True).returncode == 0
+            if not clean:
+                base = []
+                for line in open(patch_path).read(2000).splitlines():       # "# Base: <sha>" or "... Base commit: <sha>."
+                    if line.startswith("#") and "Base" in line:
+                        words = line.replace(".", " ").replace(":", " ").split()
+                        at = words.index(next(x for x in words if x.startswith("Base")))
+                        base += [w for w in words[at + 1:] if len(w) >= 7 and all(c in "0123456789abcdef" for c in w)][:1]
+                if not base:
+                    raise SystemExit("%s does not apply to today's tree and names no '# Base: <commit>'" % patch_path)
+                print("patch does not apply to HEAD: building from its base commit", base[0])
+                for d in ("cbet_raytracing_3d_amd", "include"):
+                    shutil.rmtree(os.path.join(tmp, d))
+                tar = subprocess.run(["git", "archive", base[0], "cbet_raytracing_3d_amd", "include"], cwd=ROOT, check=True, capture_output=True).stdout
+                subprocess.run(["tar", "-x", "-C", tmp], input=tar, check=True)
             subprocess.check_call(["patch", "-p1", "-s", "-i", patch_path], cwd=tmp)
             print("applied", patch_path, "(its Python parts -- api constants, tracer options -- are NOT installed: apply the patch to the tree "
                   "to drive a variant that needs them)")
