@@ -26,12 +26,19 @@
 //     8 nodes hit different LDS addresses in any one ds_add_f64; the first box stores its rows densely
 //     with a rotated z index, which spreads a bundle's nodes over the banks in 8 KB: with the second box
 //     10,240 B per wave, 16 waves per CU.
+//   * control: every lane predicate that steers the step is a 64-bit mask in scalar registers (live rays, box B's lanes,
+//     lanes outside both boxes, who moved, who flushes), combined with scalar instructions and turned into a lane
+//     condition only where lanes diverge (CBET_LANES); the loop's branches are all wave-uniform and the file is built
+//     with -mllvm -structurizecfg-skip-uniform-regions=true, so they stay plain branches (structurised, their flow
+//     blocks cost the common path ~40 scalar copies per step); one loop exit; the rare window arm works on copies and
+//     writes back through moves tied to the variables' registers (commit).
 //
 // Template parameters: WZ = z extent of a tile (16: aligned z-bricks; 8: single z-planes, used by the
 // CBET field pass whose three extra component tiles would not fit otherwise); GENERIC = run-time
 // absorption flag and 64-bit table indexing (grids of >= 2^32 table bytes, bookkeeping mode) instead
 // of the compiled-in common case; CBET = 0 none, 1 gain hooks, 2 gain hooks + the energy field deposited,
-// 4 fused four-component field pass (no reference counterpart: DESIGN.md section 9).
+// 4 fused four-component field pass (no reference counterpart: DESIGN.md section 9); STATS = also count
+// the deposit windows' diagnostics (cbet_params.window_stats).
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -61,7 +68,7 @@ struct Tile {
     //     ((z + 7 x + 3 y) & 15).  Scored with the measured cost law on oracle ray paths (scripts/deposit_layouts.py
     //     --accumulate) it equals the best padded layouts (16.1 cycles per add; rows of 18 / planes of 148: 16.4) in
     //     8,192 B instead of 9,472: with the 2 KB box B exactly the 10,240 B that give SIXTEEN waves per CU, the cap the
-    //     127 registers set anyway.  (Round 3 shipped the padding at 14 waves: rotation costs ~20 more address
+    //     125 registers set anyway.  (Round 3 shipped the padding at 14 waves: rotation costs ~20 more address
     //     instructions per flush, which mattered when every lane deposited every step.)
     //   * PAD without ROT (the 8 x 8 x 8 box of the field pass): rows of WZ + 1, planes padded by 4.
     //   * neither: dense, for the rarely used second box.

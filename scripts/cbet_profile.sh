@@ -13,6 +13,8 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows:
     name = r["Name"]
-    short = name.split("(")[0][-70:]
+    import re
+    m = re.search(r"(k_\w+(<[^>]*>)?)", name)
+    short = m.group(1) if m else name.split("(")[0][-70:]
     print("%-72s calls %5s  avg %10.3f ms  total %10.1f ms  %5s%%" % (short, r["Calls"], float(r["AverageNs"]) / 1e6, float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
 PY
