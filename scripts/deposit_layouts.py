@@ -77,6 +77,10 @@ LAYOUTS = {
     "pad 149/19 (x=5,y=3)": lambda X, Y, Z: ((X & 7) * 149 + (Y & 7) * 19 + (Z & 15)) & 15,
     "dense xor f=x+3y": lambda X, Y, Z: ((Z & 15) ^ (((X & 7) + 3 * (Y & 7)) & 15)),
     "dense xor f=3x+5y... ": lambda X, Y, Z: ((Z & 15) ^ ((3 * (X & 7) + 5 * (Y & 7)) & 15)),
+    "dense xor f=7x+3y": lambda X, Y, Z: ((Z & 15) ^ ((7 * (X & 7) + 3 * (Y & 7)) & 15)),
+    "dense xor f=(2x)^(5y)": lambda X, Y, Z: ((Z & 15) ^ ((2 * (X & 7)) ^ ((5 * (Y & 7)) & 15))),
+    "dense xor f=x^(2y) ": lambda X, Y, Z: ((Z & 15) ^ ((X & 7) ^ (2 * (Y & 7)))),
+    "dense xor f=(2x+1)... x*2^y": lambda X, Y, Z: ((Z & 15) ^ ((2 * (X & 7)) ^ (Y & 7))),
     "dense add f=3x+7y (rotate z)": lambda X, Y, Z: (((Z & 15) + 7 * (X & 7) + 3 * (Y & 7)) & 15),
     "dense add f=5x+3y": lambda X, Y, Z: (((Z & 15) + 5 * (X & 7) + 3 * (Y & 7)) & 15),
     "dense add f=4x+2y": lambda X, Y, Z: (((Z & 15) + 4 * (X & 7) + 2 * (Y & 7)) & 15),
