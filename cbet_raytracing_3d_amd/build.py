@@ -58,9 +58,8 @@ def build(force=False, verbose=False, extra_flags=()):
     if run.returncode != 0 and "structurizecfg-skip-uniform-regions" in run.stderr:
         # a compiler without the (hidden) LLVM option: the library is the same without it, the trace kernel ~6 % slower
         print("build: this hipcc does not know -structurizecfg-skip-uniform-regions; building without it", flush=True)
-        cmd = [c for c in cmd if c != "-structurizecfg-skip-uniform-regions=true"]
-        cmd = [c for i, c in enumerate(cmd) if not (c == "-mllvm" and (i + 1 >= len(cmd) or not cmd[i + 1].startswith("-")))]
-        subprocess.check_call(cmd)
+        k = cmd.index("-structurizecfg-skip-uniform-regions=true")
+        subprocess.check_call(cmd[:k - 1] + cmd[k + 1:])      # (the option and the -mllvm in front of it)
     elif run.returncode != 0:
         raise subprocess.CalledProcessError(run.returncode, cmd)
     build_cli(verbose)
