@@ -249,7 +249,6 @@ __global__ void __launch_bounds__(64, 3) k_gain_field_sym(const GainArgs a)
     const int HY = a.ny + 2, HZ = a.nz + 2;
     const long hsize = a.bstride;
     const long total = hsize * a.nbeams;
-    const int zb = (HZ + LC - 1) / LC;
     const long rows = (long)(a.hx_hi - a.hx_lo) * HY;
     const int lane = threadIdx.x, c = lane & (LC - 1), g = lane >> 4;
     const double iaw2 = a.iaw * a.iaw;
@@ -258,9 +257,15 @@ __global__ void __launch_bounds__(64, 3) k_gain_field_sym(const GainArgs a)
     double st_rt = 0.0, st_ux = 0.0, st_uy = 0.0, st_uz = 0.0, st_pref = 0.0;
     for (long row = blockIdx.x; row < rows; row += gridDim.x) {
         const int hi = a.hx_lo + (int)(row / HY), hj = (int)(row % HY);
-        for (int ibz = 0; ibz < zb; ++ibz) {
-            const int hk = LC * ibz + c;
-            const bool valid = hk < HZ;
+        // runs start on 128-byte lines of the arrays, not at z = 16 k of the row: the row's first entry sits `sft` doubles into
+        // a line (rows are nz + 2 doubles long), so the first run holds the 16 - sft cells up to the next line and every later
+        // one is exactly one line per beam and array (beams whose stride from beam 0 is an odd multiple of 8 doubles -- every
+        // second one at 256^3 -- stay half a line off: the arrays' beam stride is the caller's)
+        const int sft = (int)((((long)hi * HY + hj) * HZ - a.store0) & (LC - 1));
+        const int zb_row = (HZ + sft + LC - 1) / LC;
+        for (int ibz = 0; ibz < zb_row; ++ibz) {
+            const int hk = LC * ibz + c - sft;
+            const bool valid = hk >= 0 && hk < HZ;
             const long h = ((long)hi * HY + hj) * HZ + (valid ? hk : 0);
             const long hs = h - a.store0;
             double *fI = a.fields + hs, *fx = fI + total, *fy = fx + total, *fz = fy + total;
@@ -289,8 +294,8 @@ __global__ void __launch_bounds__(64, 3) k_gain_field_sym(const GainArgs a)
             const int n = __popcll(mask), tiles = (n + LG - 1) / LG;
             // the plasma state of 64 cells at a time (lane = cell), handed to the four runs they make up
             if ((ibz & 3) == 0) {
-                const int hk64 = LC * ibz + lane;
-                const CellState c64 = cell_state(a, ((long)hi * HY + hj) * HZ + (hk64 < HZ ? hk64 : HZ - 1));
+                const int hk64 = LC * ibz + lane - sft;
+                const CellState c64 = cell_state(a, ((long)hi * HY + hj) * HZ + (hk64 < 0 ? 0 : (hk64 < HZ ? hk64 : HZ - 1)));
                 st_rt = c64.rt; st_ux = c64.ux; st_uy = c64.uy; st_uz = c64.uz;
                 st_pref = c64.eps > 0.0 ? a.gain_const * c64.frac * (1.0 / a.iaw) / c64.rt : 0.0;
             }

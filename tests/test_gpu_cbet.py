@@ -376,8 +376,8 @@ def test_gain_update_by_slabs_equals_the_whole(api, setup, torch_cuda):
 
 def test_packed_slab_storage_equals_whole_grid_storage(api, setup, torch_cuda):
     """cbet_gain_field_packed / cbet_params.grid_beam0, grid_beams: arrays that hold only one x-slab of every beam,
-    or only some beams' grids, must give bit for bit what the whole arrays give (the storage one rank of the
-    slab-owned loop keeps)."""
+    or only some beams' grids, must give what the whole arrays give -- bit for bit for the fields, the ordered gain kernel and
+    the traces, to the last bits for the pair-once gain kernel (the storage one rank of the slab-owned loop keeps)."""
     tr, gp = setup["tr"], setup["gp"]
     stream = torch_cuda.cuda.current_stream().cuda_stream
     fields = torch_cuda.from_numpy(setup["ofields"].copy()).cuda()
@@ -392,7 +392,14 @@ def test_packed_slab_storage_equals_whole_grid_storage(api, setup, torch_cuda):
         ch = torch_cuda.zeros(2, dtype=torch_cuda.float64, device="cuda")
         api.gain_field_packed(f_pk, None, g_pk, torch_cuda.empty_like(g_pk) if sym else None, ch, x0, x1, tr.params, gp,
                               tr.ctx, stream)
-        assert torch_cuda.equal(g_pk, ref[:, x0:x1]) and torch_cuda.equal(f_pk, f_ref[:, :, x0:x1])
+        assert torch_cuda.equal(f_pk, f_ref[:, :, x0:x1])              # the normalisation is cell-local arithmetic
+        if sym:
+            # the pair-once kernel cuts a z-row into runs that start on 128-byte lines of the ARRAYS, so which cells share a
+            # run -- and with it the grouping of a cell's pair sums -- follows the storage: equal to the last bits, like
+            # against the ordered kernel
+            assert float((g_pk - ref[:, x0:x1]).abs().max()) < 1e-12 * float(ref.abs().max())
+        else:
+            assert torch_cuda.equal(g_pk, ref[:, x0:x1])
         assert float(((ch - ch_ref).abs() / ch_ref).max()) < 1e-12      # atomically accumulated: order differs
     # beams [2, 5) only: field pass and deposition pass with compact arrays against slices of the full ones
     gain = torch_cuda.from_numpy(setup["ogain"].copy()).cuda()
