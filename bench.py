@@ -121,11 +121,12 @@ def cbet_leg(api, tr, edep, n):
             "iteration": {
                 "gain_kernel": priced(prof.get("gain"), t_gain, {
                     "kernel": "k_gain_field_sym", "algorithmic_bytes": alg_gain, "algorithmic_GBps": alg_gain / t_gain / 1e9,
-                    "note": "every entry is read once, the cell's beams are staged in LDS (DESIGN.md section 9); measured traffic = "
-                            "~1.19x the workspace fetched + 0.13x written (the gain and the normalised energy entries); "
-                            "frac = (2 x FETCH_SIZE + WRITE_SIZE) / kernel time / 8 TB/s.  HBM is the nearest ceiling -- "
-                            "frac_of_measured_copy_rate is against the 6.29 TB/s the guide measures as achievable --, vector "
-                            "issue (valu_issue_frac) the second; more than half of the wave cycles wait (wave_cycles_waiting_frac)"}),
+                    "note": "every entry is read once, the cell's beams are staged in LDS, runs start on the arrays' 128-byte lines "
+                            "(DESIGN.md section 9): measured traffic = the workspace (41.2 GB) to 1 % in a frozen-direction call; "
+                            "frac = (2 x FETCH_SIZE + WRITE_SIZE) / kernel time / 8 TB/s, frac_of_measured_copy_rate against the "
+                            "6.29 TB/s the guide measures as achievable.  No ceiling is near: HBM is the nearest, vector issue "
+                            "(valu_issue_frac) next, and more than half of the wave cycles wait (wave_cycles_waiting_frac): the "
+                            "load / pair / store phases of a run overlap only with other waves' at 12 waves per CU"}),
                 "energy_field_pass": priced(prof.get("field"), t_field, {"kernel": "k_trace_window<16,false,2>"}),
                 "ms": 1e3 * (t_field + t_gain)},
             "workload": "omega60_%dcube_s83177_absorption + CBET fixed-point iteration" % n,
