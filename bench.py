@@ -274,6 +274,7 @@ def spawn_ranks(ngpus, rank_timeout):
     well inside the driver's): on expiry the whole process group of the launcher is terminated, every rank's last
     stderr lines are printed and the exit code is 124 -- a run that hangs in RCCL's set-up cannot die silently.  Every
     rank's stderr goes to a file of its own (CBET_BENCH_STDERR_DIR) and is replayed, labelled, when the run ends."""
+    import shutil
     import signal
     import socket
     import subprocess
@@ -319,8 +320,10 @@ def spawn_ranks(ngpus, rank_timeout):
             except subprocess.TimeoutExpired:
                 continue
         replay(tail=30)
+        shutil.rmtree(logdir, ignore_errors=True)
         return 124
     replay(tail=None if rc == 0 else 60)
+    shutil.rmtree(logdir, ignore_errors=True)
     return rc
 
 
