@@ -124,7 +124,9 @@ typedef struct cbet_derived {
     long nlive_rays;             /* of those, rays inside the beam radius (per beam)           */
 } cbet_derived;
 
-/* Counters a launch accumulates on the device (read back with cbet_context_counters). */
+/* Counters a launch accumulates on the device (read back with cbet_context_counters).  The default kernel fills
+ * ray_steps and rays_traced always; the other six (the deposit windows' diagnostics) only when cbet_params.window_stats
+ * is set -- they stay 0 otherwise.  The cross-check kernels (variants 1, 2) fill what applies to them. */
 typedef struct cbet_counters {
     unsigned long long ray_steps;        /* integrator iterations that reached the deposition  */
     unsigned long long rays_traced;      /* live rays launched                                 */
