@@ -173,7 +173,7 @@ class RayTracer:
             plan = engine.exchanger.plan
             rep["exchange"] = {"chunks": engine.exchanger.chunks, "messages": engine.exchanger.messages, "bytes_sent": engine.exchanger.bytes_sent,
                                "staging_bytes": engine.exchanger.staging_bytes(),
-                               "sparse": plan is not None,
+                               "sparse": plan is not None, "two_channels": engine.exchanger.two_channels,
                                "runs_per_exchange": plan.runs_out if plan is not None else None,
                                "dense_fraction": (8.0 * plan.runs_out / max(1, plan.dense_out)) if plan is not None else 1.0}
         else:
@@ -534,12 +534,25 @@ class _DeviceCbetEngine:
             torch.cuda.current_stream(self.tr.device).wait_event(self.trace_group(0, self.b1 - self.b0, use_gain, full))
         return self.own_fields
 
-    def update_gain_slab(self, frozen=False):
+    def update_gain_slab(self, frozen=False, after_piece=None):
         """The gain update of all beams over this rank's pieces; a second piece runs on a side stream beside the first (two
-        small launches one after the other would each pay their own ramp and drain)."""
+        small launches one after the other would each pay their own ramp and drain).  after_piece(k, event): the pieces
+        then run ONE AFTER THE OTHER on the current stream, `event` recorded behind piece k -- the caller sends piece k's
+        gain back while piece k + 1 updates.  (All launches are enqueued before the first call-back: enqueueing a piece's
+        messages takes the host longer than the piece's update takes the device.)"""
         self.change.zero_()
         cur = torch.cuda.current_stream(self.tr.device)
         gp = _frozen(self.gp, frozen)
+        if after_piece is not None:
+            done = []
+            for (lo, hi), fields, gain in zip(self.pieces, self.slab_fields, self.gain_slab):
+                if hi > lo:
+                    api.gain_field_packed(fields, None, gain, gain, self.change, lo, hi, self.tr.params, gp, self.tr.ctx, cur.cuda_stream)
+                done.append(torch.cuda.Event())
+                done[-1].record(cur)
+            for k, ev in enumerate(done):
+                after_piece(k, ev)
+            return self.change
         side_done = []
         for k, ((lo, hi), fields, gain) in enumerate(zip(self.pieces, self.slab_fields, self.gain_slab)):
             if hi <= lo:
@@ -679,7 +692,15 @@ def slab_pieces(layout, nx_halo, world_size, weights=None):
                evens out (modelled cost spread 1.53 -> 1.13 at 256^3 / 60 beams / 8 ranks) while every message keeps the
                same size, so no link carries more than another (twice the messages, half as long);
     a number > 1 : one slab per rank cut by the modelled gain-update cost `weights`, none wider than that multiple of the
-               equal share (balanced_slabs) -- balances better and lengthens every grouped call by the widest slab."""
+               equal share (balanced_slabs) -- balances better and lengthens every grouped call by the widest slab;
+    "halves" : the equal slab as TWO pieces (lower and upper half of its planes): the loop updates them one after the other
+               and sends the first half's gain back while the second half updates (never priced on real links)."""
+    if layout == "halves":
+        out = []
+        for lo, hi in _parts(nx_halo, world_size):
+            mid = lo + (hi - lo + 1) // 2
+            out.append([(lo, mid), (mid, hi)])          # (always two, an empty one included: the ranks exchange piece by piece)
+        return out
     if layout == "paired" and world_size > 1:
         blocks = _parts(nx_halo, 2 * world_size)
         return [[b for b in (blocks[r], blocks[world_size + r]) if b[1] > b[0]] or [(0, 0)] for r in range(world_size)]
@@ -719,7 +740,7 @@ class _SlabExchanger:
     Ranks without beams or planes simply post nothing; every rank walks the beam indices in the same order, so the
     sends and receives of a pair match in order."""
 
-    def __init__(self, device, group, rank, world_size, beams, force_collectives=False, emulate=None):
+    def __init__(self, device, group, rank, world_size, beams, force_collectives=False, emulate=None, two_channels=False):
         import torch.distributed as dist
         self.group, self.device, self.rank, self.world, self.beams = group, torch.device(device), rank, world_size, beams
         self.cuda = self.device.type == "cuda"
@@ -731,6 +752,18 @@ class _SlabExchanger:
         self.nccl = self.cuda and ((self.dist_on and dist.get_backend(group) == "nccl") or emulate is not None)
         self.force = force_collectives      # one rank: the same send/recv machinery as a self-exchange (RCCL smoke test)
         self.stream = torch.cuda.Stream(device=self.device) if self.nccl else None
+        # two_channels: exchange 2 (the gain's way back) gets a communicator and a stream of its own, so that a pass's fields
+        # do not queue behind the previous pass's gain on one in-order channel (every rank creates the second group here, in
+        # the same place of its program: new_group is collective)
+        self.group2, self.stream2 = group, self.stream
+        self.two_channels = False
+        if two_channels and emulate is not None:
+            self.stream2, self.two_channels = (torch.cuda.Stream(device=self.device) if self.nccl else None), True
+        elif two_channels and self.dist_on and (world_size > 1 or force_collectives):
+            self.two_channels = True
+            ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
+            self.group2 = dist.new_group(ranks=ranks, backend=dist.get_backend(group))
+            self.stream2 = torch.cuda.Stream(device=self.device) if self.nccl else None
         self.solo = world_size == 1
         self.peers = [rank] if (self.solo and self.force) else [r for r in range(world_size) if r != rank]
         self.slabs = None
@@ -751,29 +784,32 @@ class _SlabExchanger:
         import torch.distributed as dist
         return r if self.group is None else dist.get_global_rank(self.group, r)
 
-    def _enter(self, after):
-        """Order what follows behind the events in `after`: on the communication stream (RCCL) or the current one."""
-        target = self.stream if self.nccl else (torch.cuda.current_stream(self.device) if self.cuda else None)
+    def _enter(self, after, back=False):
+        """Order what follows behind the events in `after`: on the communication stream (RCCL) -- the second channel's for
+        the gain's way back (`back`) -- or the current one."""
+        cs = self.stream2 if back else self.stream
+        target = cs if self.nccl else (torch.cuda.current_stream(self.device) if self.cuda else None)
         if target is not None:
             for ev in after:
                 if ev is not None:
                     target.wait_event(ev)
-        return torch.cuda.stream(self.stream) if self.nccl else _NullContext()
+        return torch.cuda.stream(cs) if self.nccl else _NullContext()
 
-    def _leave(self):
-        """An event behind everything issued so far (None without a device)."""
+    def _leave(self, back=False):
+        """An event behind everything issued so far on that channel (None without a device)."""
         if not self.cuda:
             return None
         ev = torch.cuda.Event()
-        ev.record(self.stream if self.nccl else torch.cuda.current_stream(self.device))
+        ev.record((self.stream2 if back else self.stream) if self.nccl else torch.cuda.current_stream(self.device))
         return ev
 
     def fence(self):
         return self._leave()
 
-    def _batch(self, sends, recvs):
+    def _batch(self, sends, recvs, back=False):
         """One grouped send/recv: `sends` / `recvs` are (tensor view, peer) lists of contiguous views."""
         import torch.distributed as dist
+        group = self.group2 if back else self.group
         if not sends and not recvs:
             return
         if self.emulate is not None:
@@ -786,14 +822,14 @@ class _SlabExchanger:
         for t, peer in sends:
             if self.cuda and not self.nccl:
                 t = t.cpu()                         # gloo: through the host (synchronises the current stream)
-            ops.append(dist.P2POp(dist.isend, t, self._global(peer), self.group))
+            ops.append(dist.P2POp(dist.isend, t, self._global(peer), group))
             self.bytes_sent += 8 * t.numel()
         for t, peer in recvs:
             if self.cuda and not self.nccl:
                 h = torch.empty(t.shape, dtype=t.dtype, device="cpu")
                 late.append((t, h))
                 t = h
-            ops.append(dist.P2POp(dist.irecv, t, self._global(peer), self.group))
+            ops.append(dist.P2POp(dist.irecv, t, self._global(peer), group))
         for req in dist.batch_isend_irecv(ops):
             req.wait()     # RCCL: the communication stream waits (no host block); gloo: the host waits
         for t, h in late:
@@ -825,28 +861,33 @@ class _SlabExchanger:
                 self._batch(sends, recvs)
         return self._leave()
 
-    def gain_back(self, gain_slab, gain_own, i0, i1, after=()):
+    def gain_back(self, gain_slab, gain_own, i0, i1, after=(), only_piece=None):
         """Exchange 2 for the beams with index [i0, i1): the new gain of rank q's beams over my pieces -> rank q, my beams'
         gain over rank s's pieces <- rank s.  gain_slab: one [all beams][piece planes][Y][Z] per piece of mine; gain_own:
-        [my beams][X][Y][Z].  Returns the event behind it: the next pass's trace of these beams waits for it."""
+        [my beams][X][Y][Z].  only_piece = k: the k-th piece of EVERY rank alone (the loop sends a half slab's gain while the
+        other half still updates; every rank has the same number of pieces then).  Runs on the second channel when there is
+        one.  Returns the event behind it: the next pass's trace of these beams waits for it."""
         rank, beams, pieces = self.rank, self.beams, self.slabs
         b0, b1 = beams[rank]
-        with self._enter(after):
+
+        def want(k):
+            return only_piece is None or k == only_piece
+        with self._enter(after, back=True):
             for i in range(i0, i1):
                 sends, recvs = [], []
                 mine = i < b1 - b0
                 for q in self.peers:
                     q0, q1 = beams[q]
                     if i < q1 - q0:
-                        sends += [(gain_slab[k][q0 + i], q) for k, (lo, hi) in enumerate(pieces[rank]) if hi > lo]
+                        sends += [(gain_slab[k][q0 + i], q) for k, (lo, hi) in enumerate(pieces[rank]) if hi > lo and want(k)]
                     if mine:
-                        recvs += [(gain_own[i, lo:hi], q) for lo, hi in pieces[q] if hi > lo]
+                        recvs += [(gain_own[i, lo:hi], q) for k, (lo, hi) in enumerate(pieces[q]) if hi > lo and want(k)]
                 if mine and not (self.solo and self.force):
                     for k, (lo, hi) in enumerate(pieces[rank]):
-                        if hi > lo:
+                        if hi > lo and want(k):
                             gain_own[i, lo:hi].copy_(gain_slab[k][b0 + i])
-                self._batch(sends, recvs)
-        return self._leave()
+                self._batch(sends, recvs, back=True)
+        return self._leave(back=True)
 
     # ---- the sparse form: only the 64-byte z-runs inside the beams' footprints move (SegmentPlan) --------------------
     def use_plan(self, plan):
@@ -1021,7 +1062,7 @@ class _NullContext:
 
 
 def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_size=1, group=None, sparse=False,
-                           trace_groups=4, slab_layout="equal"):
+                           trace_groups=4, slab_layout="equal", two_channels=False):
     """The CBET fixed-point iteration with storage, exchange and schedule sized for 8 ranks on point-to-point xGMI (SURVEY
     8(f) f1; parity unpinned; same passes and same result as cbet_fixed_point).
 
@@ -1040,6 +1081,11 @@ def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_s
     grouped send/recv lasts as long as its largest message, which goes to the widest slab (1.6 x), and at the 64 GB/s the
     links are priced with that costs more than the balance saves.  Neither moves the iteration outside the noise of the
     one-GPU emulation (scripts/cbet_rank_share.py, profiles/r4/cbet_rank_share.log); the simplest stays the default.
+    "halves": the equal slab updated as its lower and its upper half one after the other, the lower half's gain on its way
+    back while the upper half updates.  two_channels=True: the gain's way back gets its own communicator and stream, so a
+    pass's fields never queue behind gain messages.  Both are schedule changes only (same arithmetic on the same cells;
+    equality tests at 2 and 3 ranks) and neither has been priced: that needs real links, the one-GPU emulation shares one
+    copy engine between the "channels".
 
     One pass, pipelined over beam GROUPS (trace_groups of them; engine.trace_group rotates them over its trace streams):
         trace group g  ->  exchange 1 of group g's beams (while the later groups trace): my beams' fields over slab s to
@@ -1052,7 +1098,7 @@ def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_s
     inside the beams' footprints (SegmentPlan; exact; does not pay for this physics, see profiles/r3/cbet_rank_share.log).
     `engine`: begin_beams(b0, b1); trace_group(i0, i1, use_gain, full, wait) -> event or None; presence_counts() ->
     integer [X][Y][Z]; begin_slab(pieces); attributes own_fields, gain_own, slab_fields, gain_slab (lists, one per piece);
-    update_gain_slab(frozen) -> tensor {sum |dK|, sum |K|} over the slab; deposit_beams() -> beam_gain.  The
+    update_gain_slab(frozen[, after_piece]) -> tensor {sum |dK|, sum |K|} over the slab; deposit_beams() -> beam_gain.  The
     deposition grid is left un-reduced (allreduce_grid / reduce_scatter_grid)."""
     import torch.distributed as dist
     beams = _parts(nbeams, world_size)
@@ -1063,7 +1109,7 @@ def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_s
     force = getattr(engine, "force_collectives", False)   # one rank, but every collective really runs (RCCL smoke test)
     engine.begin_beams(b0, b1)
     xch = _SlabExchanger(engine.own_fields.device, group, rank, world_size, beams, force_collectives=force,
-                         emulate=getattr(engine, "emulate_transport", None))
+                         emulate=getattr(engine, "emulate_transport", None), two_channels=two_channels)
     engine.exchanger = xch
     on_device = engine.own_fields.is_cuda
     cur = (lambda: torch.cuda.current_stream(engine.own_fields.device)) if on_device else None
@@ -1128,7 +1174,7 @@ def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_s
             if j1 > j0:
                 traced[k] = engine.trace_group(j0, j1, it > 0, full, wait=(gain_ev[k],))
             if slabs is not None and plan is None and k >= LAG:
-                xch.fields_out(engine.own_fields, engine.slab_fields, *groups[k - LAG], comps, after=(traced[k - LAG],))
+                xch.fields_out(engine.own_fields, engine.slab_fields, *groups[k - LAG], comps, after=(traced[k - LAG], updated))
         if slabs is None:
             # first pass: the beams' footprints are known now -- cut the slabs, allocate them, then send everything
             wait_here(traced)
@@ -1159,10 +1205,20 @@ def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_s
                            ncomp=len(comps), after=list(traced) + [allocated])
         else:
             for k in range(first, G):
-                xch.fields_out(engine.own_fields, engine.slab_fields, *groups[k], comps, after=(traced[k], allocated))
+                # (`updated`: a rank without a beam in this group has no trace to wait for, and with two channels nothing
+                # else keeps the peers' fields out of slab_fields while the previous update still reads them)
+                xch.fields_out(engine.own_fields, engine.slab_fields, *groups[k], comps, after=(traced[k], allocated, updated))
         allocated = None
         wait_here([xch.fence()])                     # every beam's fields over my slab are in
-        ch = engine.update_gain_slab(not full)
+        if xch.two_channels:
+            wait_here(gain_ev)                       # ... and the previous gain has left gain_slab (one channel: in order)
+        split = slab_layout == "halves" and plan is None
+
+        def piece_done(kp, ev):
+            # the gain of piece kp is final behind `ev`: all groups' share of it goes back, while the next piece updates
+            for k in range(G):
+                gain_ev[k] = xch.gain_back(engine.gain_slab, engine.gain_own, *groups[k], after=(ev,), only_piece=kp)
+        ch = engine.update_gain_slab(not full, after_piece=piece_done) if split else engine.update_gain_slab(not full)
         updated = mark()
         # the gain of rank q's beams over my slab -> rank q; my beams' gain over slab s <- rank s.  It is due whatever the
         # convergence scalars say (the deposition pass needs the new gain too): the head goes out now
@@ -1170,6 +1226,8 @@ def cbet_fixed_point_slabs(engine, gain_params, nbeams, nx_halo, rank=0, world_s
             ev = xch.run_sparse(engine.gain_slab[0], lambda q: (slice(*beams[q]),),
                                 engine.gain_own, lambda s_: (slice(None), slice(*slabs[s_])), False, after=(updated,))
             gain_ev, owed = [ev] * G, []
+        elif split:
+            owed = []                                # (went back piece by piece, see piece_done)
         else:
             for k in range(HEAD):
                 gain_ev[k] = send_gain(k)

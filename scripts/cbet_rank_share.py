@@ -12,7 +12,7 @@ stand-in for it (`emulate`): on the communication stream, exactly where RCCL's g
 Kernels, copies, stream order and host round trips are real; only the link time is a model, and it is stated.
 The slabs are cut by gain-update work from the reference solve's beam counts, as the loop cuts them.
 
-usage: python scripts/cbet_rank_share.py [W=8] [n=256] [link GB/s per direction per peer = 64] [trace groups = 4] [ranks = 0,3,7] [slab layout = equal | paired | a number > 1]
+usage: python scripts/cbet_rank_share.py [W=8] [n=256] [link GB/s per direction per peer = 64] [trace groups = 4] [ranks = 0,3,7] [slab layout = equal | paired | halves | a number > 1] [channels = 1 | 2]
 """
 import os
 import sys
@@ -31,8 +31,9 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 LINK = float(sys.argv[3]) if len(sys.argv) > 3 else 64.0      # GB/s per direction per peer link, what RCCL send/recv is assumed to sustain
 GROUPS = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 RANKS = [int(x) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 else sorted({0, W // 2 - 1 if W > 1 else 0, W - 1})
+CHANNELS = int(sys.argv[7]) if len(sys.argv) > 7 else 1        # 2: exchange 2 on a stream of its own (tracer.cbet_fixed_point_slabs two_channels)
 LAYOUT = sys.argv[6] if len(sys.argv) > 6 else "equal"        # tracer.slab_pieces: "paired", "equal", or the widest slab of a work-balanced cut (x the equal share)
-LAYOUT = LAYOUT if LAYOUT in ("paired", "equal") else float(LAYOUT)
+LAYOUT = LAYOUT if LAYOUT in ("paired", "equal", "halves") else float(LAYOUT)
 CALL_US = 15.0                                                 # fixed cost of one grouped send/recv (launch + handshake)
 nb = 60
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -168,11 +169,11 @@ class EmulatedEngine(T._DeviceCbetEngine):
         self.trace_ends.setdefault(len(self.marks), []).append(ev)
         return done
 
-    def update_gain_slab(self, frozen=False):
+    def update_gain_slab(self, frozen=False, after_piece=None):
         self.host_t.append(["update", time.perf_counter()])
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         ev[0].record()
-        out = super().update_gain_slab(frozen)
+        out = super().update_gain_slab(frozen, after_piece)
         ev[1].record()
         self.marks.append(ev)
         if len(self.marks) > 2:
@@ -186,7 +187,7 @@ def run_rank(rank, link, groups, layout, passes=7):
     g.tolerance, g.max_passes = 0.0, passes
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    rep = T.cbet_fixed_point_slabs(eng, g, nb, X, rank, W, None, trace_groups=groups, slab_layout=layout)
+    rep = T.cbet_fixed_point_slabs(eng, g, nb, X, rank, W, None, trace_groups=groups, slab_layout=layout, two_channels=CHANNELS == 2)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     starts = [m[0] for m in eng.marks]
@@ -277,7 +278,7 @@ for rank in RANKS:
         free = run_rank(rank, 0.0, GROUPS, LAYOUT)     # the same schedule with free links: what the exchanges still cost in it
         flat = run_rank(rank, LINK, 1, "equal")        # one group, one equal slab: nothing overlapped, the round-3 shape
     alts = {} if os.environ.get("CBET_SHARE_MAIN_ONLY") else \
-        {(gr, ba): run_rank(rank, LINK, gr, ba)["iteration"] for gr in (4, 8) for ba in ("equal", "paired", 1.15, 9.0) if (gr, ba) != (GROUPS, LAYOUT)}
+        {(gr, ba): run_rank(rank, LINK, gr, ba)["iteration"] for gr in (4, 8) for ba in ("equal", "paired", "halves", 1.15, 9.0) if (gr, ba) != (GROUPS, LAYOUT)}
     alts[(GROUPS, LAYOUT)] = res["iteration"]
     rows.append(res)
     print("rank %d: beams [%d,%d), planes %s  -- workspace %.2f GB" % (rank, *res["beams"], " + ".join("[%d,%d)" % pc for pc in res["slab"]), res["bytes"] / 1e9))

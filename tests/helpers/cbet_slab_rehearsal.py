@@ -20,9 +20,11 @@ beams = [0, 9, 16, 29, 38, 47, 55]
 tr = RayTracer(api.default_params(n, nbeams=len(beams)), r, ne, te, beam_norm=bn[beams])
 gp = api.default_gain_params(relax=1.0, tolerance=1e-6, max_passes=12)
 out = {}
-for name, slabs in (("all-reduce", False), ("slabs", True)):
+layouts = dict(slab_layout=1.4, trace_groups=2) if world == 3 else dict(slab_layout="paired")
+for name, slabs, opts in (("all-reduce", False, {}), ("slabs", True, layouts),
+                          ("halves+2ch", True, dict(slab_layout="halves", two_channels=True, trace_groups=3))):
     e = tr.new_grid()
-    rep = tr.cbet_solve(e, gp, rank=rank, world_size=world, slabs=slabs, **(dict(slab_layout=1.4, trace_groups=2) if (slabs and world == 3) else (dict(slab_layout="paired") if slabs else {})))
+    rep = tr.cbet_solve(e, gp, rank=rank, world_size=world, slabs=slabs, **opts)
     allreduce_grid(e)
     out[name] = (e.cpu().numpy(), rep)
 if rank == 0:

@@ -69,16 +69,20 @@ trc = RayTracer(api.default_params(32, nbeams=len(beams)), r, ne, te, beam_norm=
 gp = api.default_gain_params(relax=1.0, tolerance=1e-6, max_passes=12)
 e0 = trc.new_grid()
 rep0 = trc.cbet_solve(e0, gp)
-for name, slabs, sparse in (("all-reduce loop", False, False), ("slab loop (dense exchanges: one message per beam, peer and component, all peers of a beam in one grouped send/recv)", True, False),
-                            ("slab loop (sparse exchanges: pack / send-recv / unpack of z-runs)", True, True)):
+for name, slabs, sparse, opts in (("all-reduce loop", False, False, {}), ("slab loop (dense exchanges: one message per beam, peer and component, all peers of a beam in one grouped send/recv)", True, False, {}),
+                                  ("slab loop (sparse exchanges: pack / send-recv / unpack of z-runs)", True, True, {}),
+                                  ("slab loop (update split by plane halves, exchange 2 on a second RCCL communicator and stream)", True, False,
+                                   dict(slab_layout="halves", two_channels=True))):
     e = trc.new_grid()
-    rep = trc.cbet_solve(e, gp, slabs=slabs, force_collectives=True, sparse=sparse)
+    rep = trc.cbet_solve(e, gp, slabs=slabs, force_collectives=True, sparse=sparse, **opts)
     allreduce_grid(e, force=True)
     torch.cuda.synchronize()
     err = parity_err(e.cpu().numpy(), e0.cpu().numpy())
     extra = ""
     if slabs:
         x = rep.get("exchange", {})
+        if opts:
+            ok &= bool(x.get("two_channels")) and all(len(pcs) == 2 for pcs in rep["slabs"])
         extra = " %s grouped send/recvs, %s messages, %.1f MB sent, staging %d B" % (x.get("chunks"), x.get("messages"), x.get("bytes_sent", 0) / 1e6, x.get("staging_bytes", 0))
     check("CBET " + name, err < 1e-9 and rep["passes"] == rep0["passes"] and rep["converged"],
           "passes %d, max rel err %.1e%s" % (rep["passes"], err, extra))

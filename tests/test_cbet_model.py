@@ -272,8 +272,10 @@ class _OracleEngine:
             self.own_fields[c, i0:i1] = torch.from_numpy(np.ascontiguousarray(F[self.b0 + i0:self.b0 + i1]))
         return None
 
-    def update_gain_slab(self, frozen=False):
-        # the oracle updates whole grids: embed the rank's pieces (zero fields elsewhere), keep the pieces of the result
+    def update_gain_slab(self, frozen=False, after_piece=None):
+        # the oracle updates whole grids: embed the rank's pieces (zero fields elsewhere), keep the pieces of the result.
+        # after_piece(k, event) (slab_layout "halves"): piece k's new gain is stored only just before the call, so a loop that
+        # sent a piece ahead of its update would send the old gain and fail the equality test
         gs = self.O.grid_shape(self.cfg)
         F = np.zeros((4, self.nb) + gs)
         old = np.zeros((self.nb,) + gs)
@@ -282,11 +284,14 @@ class _OracleEngine:
             old[:, lo:hi] = g.numpy()
         new, _ = self.O.gain_field(self.cfg, self.g, F, self.ne3d, relax=1.0, gain=old.copy(), nthreads=2)
         ch = [0.0, 0.0]
-        for (lo, hi), g in zip(self.pieces, self.gain_slab):
+        for k, ((lo, hi), g) in enumerate(zip(self.pieces, self.gain_slab)):
             sl = new[:, lo:hi]
             ch[0] += np.abs(sl - g.numpy()).sum()
             ch[1] += np.abs(sl).sum()
             g.copy_(torch.from_numpy(np.ascontiguousarray(sl)))
+            if after_piece is not None:
+                self.pieces_announced.append(k)
+                after_piece(k, None)
         return torch.tensor(ch, dtype=torch.float64)
 
     def deposit_beams(self):
@@ -297,7 +302,7 @@ class _OracleEngine:
         return torch.from_numpy(bg)
 
 
-def _solve(rank, world, group=None, slabs=False, sparse=False):
+def _solve(rank, world, group=None, slabs=False, sparse=False, variant=None):
     sys.path.insert(0, ROOT)
     from cbet_raytracing_3d_amd import api
     from cbet_raytracing_3d_amd.tracer import allreduce_grid, cbet_fixed_point, cbet_fixed_point_slabs
@@ -311,6 +316,9 @@ def _solve(rank, world, group=None, slabs=False, sparse=False):
         # (three ranks: ONE slab per rank cut by gain-update work, at most 1.5 x the equal share wide, in three trace groups;
         # else the paired layout -- two pieces per rank --, or one equal slab under the sparse plan)
         opts = dict(slab_layout=1.5, trace_groups=3) if world == 3 else dict(slab_layout="paired")
+        if variant:     # "halves": the update split by plane halves; "+2ch": exchange 2 on a process group of its own
+            opts = dict(slab_layout="halves", trace_groups=3 if world == 3 else 2, two_channels="2ch" in variant)
+        eng.pieces_announced = []
         rep = cbet_fixed_point_slabs(eng, gp, len(BEAMS), N + 2, rank, world, group, sparse=sparse, **opts)
         eng.gain = eng.gain_own.numpy()          # this rank's beams over the whole grid
         # what the rank stored: (5 nb_r + 5 nb / W) grids = 10 nb / W: the whole problem's 5 nb at two ranks, less beyond
@@ -321,7 +329,10 @@ def _solve(rank, world, group=None, slabs=False, sparse=False):
         assert [tuple(pc) for pc in cut[rank]] == eng.pieces
         planes = sorted(x for pcs in cut for lo, hi in pcs for x in range(lo, hi))
         assert planes == list(range(N + 2))
-        assert all(len(pcs) == (2 if (world == 2 and not sparse) else 1) for pcs in cut)
+        assert all(len(pcs) == (2 if ((world == 2 or variant) and not sparse) else 1) for pcs in cut)
+        if variant:
+            assert eng.pieces_announced == [0, 1] * rep["passes"]
+            assert eng.exchanger.two_channels == ("2ch" in variant and world > 1)
         assert eng.groups_traced >= rep["passes"] * min(len(rep["groups"]), 1)
         if world > 1 and not sparse:
             xch = eng.exchanger
@@ -347,11 +358,11 @@ def _solve(rank, world, group=None, slabs=False, sparse=False):
     return rep, edep.numpy(), int(steps[0]), eng.gain
 
 
-def _worker(rank, world, port, out_dir, slabs=False, sparse=False):
+def _worker(rank, world, port, out_dir, slabs=False, sparse=False, variant=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        rep, edep, steps, gain = _solve(rank, world, slabs=slabs, sparse=sparse)
+        rep, edep, steps, gain = _solve(rank, world, slabs=slabs, sparse=sparse, variant=variant)
         if rank == 0:
             np.savez(os.path.join(out_dir, "out.npz"), edep=edep, steps=steps, gain=gain, passes=rep["passes"],
                      converged=rep["converged"], beam_gain=rep["beam_gain"], imbalance=rep["imbalance"])
@@ -403,13 +414,16 @@ def test_two_mirror_beams_exchange_nothing_net(oracle, inputs):
     assert ratio[32] < 0.15 and ratio[48] < 0.02 and ratio[48] < ratio[32]
 
 
-@pytest.mark.parametrize("world,sparse", [(2, False), (3, False), (2, True)])
-def test_slab_owned_iteration_equals_unsharded(tmp_path, api, oracle, world, sparse):
+@pytest.mark.parametrize("world,sparse,variant", [(2, False, None), (3, False, None), (2, True, None),
+                                                  (2, False, "halves"), (3, False, "halves+2ch"), (2, False, "halves+2ch")])
+def test_slab_owned_iteration_equals_unsharded(tmp_path, api, oracle, world, sparse, variant):
     """tracer.cbet_fixed_point_slabs over gloo: whole beams per rank, the gain update per x-slab, two point-to-point
     exchanges per pass instead of the all-reduce of every beam's fields -- same passes, same result; with the dense
-    chunked exchanges (the default) and with the sparse ones (only the z-runs inside the beams' footprints move)."""
-    port = 29700 + (os.getpid() % 250) + world + (7 if sparse else 0)
-    mp.spawn(_worker, args=(world, port, str(tmp_path), True, sparse), nprocs=world, join=True)
+    chunked exchanges (the default) and with the sparse ones (only the z-runs inside the beams' footprints move); with the
+    update split by plane halves (the lower half's gain sent while the upper updates) and with exchange 2 on a second
+    process group."""
+    port = 29700 + (os.getpid() % 250) + world + (7 if sparse else 0) + (11 * len(variant) if variant else 0)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), True, sparse, variant), nprocs=world, join=True)
     got = np.load(tmp_path / "out.npz")
     rep, edep, steps, gain = _solve(0, 1)
     assert rep["converged"] and bool(got["converged"]) and int(got["passes"]) == rep["passes"]

@@ -1,6 +1,7 @@
 """Multi-rank CBET loops with the real device engine: W ranks share the one GPU (gloo carries the exchanges; RCCL
 needs one device per rank), every rank runs RayTracer.cbet_solve in the all-reduce form and in the slab-owned
-form, and the combined result must equal a single-rank solve (tests/helpers/cbet_slab_rehearsal.py)."""
+form -- also with the update split by plane halves and exchange 2 on a second process group --, and the combined result
+must equal a single-rank solve (tests/helpers/cbet_slab_rehearsal.py)."""
 import os
 import subprocess
 import sys
@@ -20,7 +21,7 @@ def test_multi_rank_loops_equal_single_rank(world):
     run = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     lines = [l for l in run.stdout.splitlines() if "world" in l or "REHEARSAL" in l]
     assert run.returncode == 0 and "REHEARSAL PASS" in run.stdout, "\n".join(lines) + run.stderr[-1500:]
-    assert len([l for l in lines if l.rstrip().endswith("ok")]) == 2
+    assert len([l for l in lines if l.rstrip().endswith("ok")]) == 3       # all-reduce, slab-owned, slab-owned split + two channels
 
 
 def test_config5_rank_share_is_allocated_and_run_at_512():
