@@ -49,8 +49,9 @@ def _worker(rank, world, port, n, nbeams, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_pass_equals_unsharded(tmp_path, oracle, world):
+    # (8: the driver's scaling run -- 5 beams' bundles over 8 contiguous shares, 34 planes padded to 40 for the slab combine)
     n, nbeams = 32, 5
     port = 29500 + (os.getpid() % 500) + world
     mp.spawn(_worker, args=(world, port, n, nbeams, str(tmp_path)), nprocs=world, join=True)
