@@ -282,7 +282,11 @@ class SweepPipeline:
         self.s_trace = [torch.cuda.Stream(device=dev) for _ in range(2)]
         if not self.overlap_traces:
             self.s_trace[1] = self.s_trace[0]
+        # (one rank: the "combine" is a copy of the grid into the slab store, on the trace stream.  On a stream of its own,
+        # like RCCL's, the next trace starts right behind this one -- and the pass takes 13.2-13.3 ms instead of 13.0: the copy
+        # and the next pass's preparation then run beside the kernel's first wave generation.  Measured in round 5, not kept.)
         self.ev_prep = [torch.cuda.Event() for _ in range(2)]
+        self.ev_consumed = [None, None]      # release(b): a reader's event the next combine into slab b waits for
         self.ev_trace = [None, None]
         self.work = [None, None]
         self.kernel_events = []
@@ -316,6 +320,9 @@ class SweepPipeline:
             if timed:
                 e1.record()
                 self.kernel_events.append((e0, e1))
+            consumed, self.ev_consumed[b] = self.ev_consumed[b], None
+            if consumed is not None:
+                self.s_trace[b].wait_event(consumed)       # (behind the trace launch: only the combine waits for the reader)
             self.work[b] = reduce_scatter_grid(self.grids[b], self.slab_store[b], self.group, async_op=True, force=self.force)
             # "grid b may be cleared again": recorded AFTER the combine was enqueued -- on one rank (and with gloo) the
             # combine is a copy on this very stream, and pass k+2's grid.zero_() must not overtake it; with RCCL the
@@ -323,6 +330,22 @@ class SweepPipeline:
             self.ev_trace[b] = torch.cuda.Event()
             self.ev_trace[b].record()
         return b
+
+    def wait_combined(self, b):
+        """Make torch's current stream wait for the combine of buffer set b's last pass: behind it `slabs[b]` is complete (the
+        RCCL collective's work handle, or the event behind the local copy)."""
+        cur = torch.cuda.current_stream(self.tr.device)
+        if self.work[b] is not None:
+            self.work[b].wait()
+        if self.ev_trace[b] is not None:
+            cur.wait_event(self.ev_trace[b])
+
+    def release(self, b):
+        """A reader of `slabs[b]` on torch's current stream is done with it (enqueued so far): the next combine into that slab --
+        two passes on -- waits for this point instead of relying on being later anyway."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.tr.device))
+        self.ev_consumed[b] = ev
 
     def time_trace_alone(self, reps=3):
         """Average duration (seconds) of this rank's trace launch when NOTHING else runs beside it: with more than one

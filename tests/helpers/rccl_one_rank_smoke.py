@@ -57,8 +57,9 @@ pipe.warm()
 copies = []
 for _ in range(5):
     b = pipe.run_pass()
-    pipe.work[b].wait()                                      # this stream waits for the collective, not the host
+    pipe.wait_combined(b)                                    # this stream waits for the collective, not the host
     copies.append(pipe.slabs[b].clone())
+    pipe.release(b)
 last = pipe.finish()
 errs = [parity_err(c.cpu().numpy()[: n + 2], ref) for c in copies + [last]]
 check("SweepPipeline, 5 passes, RCCL reduce-scatter per pass", max(errs) < 1e-11, "max rel err %.1e" % max(errs))

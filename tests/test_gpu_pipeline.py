@@ -39,8 +39,9 @@ def test_every_pass_of_the_pipeline_is_complete(api, inputs, torch_cuda, overlap
     copies = []
     for _ in range(6):
         b = pipe.run_pass()
-        with torch_cuda.cuda.stream(pipe.s_trace[b]):      # stream-ordered behind this pass's combine
-            copies.append(pipe.slabs[b].clone())
+        pipe.wait_combined(b)                               # this stream waits for the pass's combine, not the host
+        copies.append(pipe.slabs[b].clone())
+        pipe.release(b)                                     # ... and the combine two passes on waits for this copy
     last = pipe.finish()
     copies.append(last.clone())
     for k, c in enumerate(copies):
