@@ -57,26 +57,40 @@ namespace {
 #define CBET_BALLOT(cond) __builtin_amdgcn_ballot_w64(cond)
 
 // A wave-private tile of fp64 accumulators covering WX x WY x WZ nodes (powers of two), addressed toroidally.
-template <int WX_, int WY_, int WZ_, bool PAD>
+template <int WX_, int WY_, int WZ_, bool PAD, bool XORSW = false>
 struct Tile {
     static constexpr int WX = WX_, WY = WY_, WZ = WZ_;
     static constexpr int XM = WX - 1, YM = WY - 1, ZM = WZ - 1;
     // Layout (doubles).  One ds_add_f64 costs the CU 8.3 cycles + 2 per extra lane on the busiest bank of each 16-lane
     // group (bank = slot mod 16; same address or not makes little difference: scripts/ubench/lds_pattern_cost.hip), and a
     // bundle's footprint is a few nodes wide per axis: stored plainly, its nodes pile up on the banks of a few z values.
-    //   * the 8 x 8 x 16 box (ROT): DENSE rows of 16 whose z index is ROTATED by 7 x + 3 y -- slot = 128 x + 16 y +
-    //     ((z + 7 x + 3 y) & 15).  Scored with the measured cost law on oracle ray paths (scripts/deposit_layouts.py
-    //     --accumulate) it equals the best padded layouts (16.1 cycles per add; rows of 18 / planes of 148: 16.4) in
-    //     8,192 B instead of 9,472: with the 2 KB box B exactly the 10,240 B that give SIXTEEN waves per CU, the cap the
-    //     125 registers set anyway.  (Round 3 shipped the padding at 14 waves: rotation costs ~20 more address
-    //     instructions per flush, which mattered when every lane deposited every step.)
+    //   * the 8 x 8 x 16 box (ROT): DENSE rows of 16 whose z index is SWIZZLED by x and y.  Scored with the measured
+    //     cost law on oracle ray paths (scripts/deposit_layouts.py --accumulate [--xorsep]) both swizzles below equal the
+    //     best padded layouts (16.4 / 16.6 cycles per add; rows of 18 / planes of 148: 16.9) in 8,192 B instead of
+    //     9,472: with the 2 KB box B exactly the 10,240 B that give SIXTEEN waves per CU, the cap the registers set anyway.
+    //       XORSW (the plain trace): slot = 128 x + 16 y + (z ^ (4 x & 15) ^ 2 y).  An exclusive-or whose x and y terms
+    //         are separate makes a node's byte offset ONE three-input v_bitop3 of a per-x, a per-y and a per-z term
+    //         (lds_add8): 22 address instructions per flush where the rotation takes 34 (12.70 against 12.95 ms).
+    //       otherwise (the CBET kernels): slot = 128 x + 16 y + ((z + 7 x + 3 y) & 15), round 4's rotation.  They sit at
+    //         128 registers; with the exclusive-or form the energy-field pass spills a constant of its phi series, reloads
+    //         it inside the step and takes 22.2 ms instead of 20.2.
     //   * PAD without ROT (the 8 x 8 x 8 box of the field pass): rows of WZ + 1, planes padded by 4.
     //   * neither: dense, for the rarely used second box.
     static constexpr bool ROT = PAD && WZ == 16;
     static constexpr int YS = (PAD && !ROT) ? WZ + 1 : WZ;
     static constexpr int XS = (PAD && !ROT) ? WY * YS + 4 : WY * WZ;
     // the z index inside a row: tile coordinates in, position in the row out
-    static __device__ __forceinline__ int zr(int tx, int ty, int tz) { return ROT ? ((tz + 7 * tx + 3 * ty) & ZM) : tz; }
+    static constexpr bool XOR = ROT && XORSW;
+    static __device__ __forceinline__ int zr(int tx, int ty, int tz)
+    {
+        return XOR ? (tz ^ ((tx & 3) << 2) ^ (ty << 1)) : (ROT ? ((tz + 7 * tx + 3 * ty) & ZM) : tz);
+    }
+    // ... as byte-offset terms whose exclusive-or is the slot's byte offset (x, y, z masked tile coordinates): the x term
+    // carries x's field and (4 x & 15) << 3 -- one multiply, the stray third bit of x << 5 cleared --, the y term y's field
+    // and 2 y << 3
+    static_assert(!XOR || (WX == 8 && WY == 8 && WZ == 16), "the swizzle terms are written for the 8 x 8 x 16 box");
+    static __device__ __forceinline__ int xterm(int tx) { return __mul24(tx, XS * 8 + 32) & ~0x80; }
+    static __device__ __forceinline__ int yterm(int ty) { return __mul24(ty, YS * 8 + 16); }
     static constexpr int N = WX * XS;           // doubles per tile
     // largest offset of a lane's low corner from the origin at which its two nodes still lie inside
     static constexpr int SX = WX - 2, SY = WY - 2, SZ = WZ - 2;
@@ -539,7 +553,7 @@ constexpr double kFarJump = 1.4998;   // relocate_deep_interior's validity bound
 template <int WZ, bool GENERIC, int CBET, bool STATS>
 __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(const TraceArgs a)
 {
-    using T = Tile<8, 8, WZ, true>;   // box A
+    using T = Tile<8, 8, WZ, true, CBET == 0>;   // box A
     // Box B holds the few lanes that left A: 4 x 8 x 8 nodes in the dense layout, 2 KB.  Occupancy is what this
     // loop responds to (256^3 pass, round 2: 25.7 ms at 8 waves per CU, 21.9 at 11, 20.9 at 12, 19.3 at 14; round 4: 16.3
     // at 14, 15.7 at 16), and the LDS is what caps it: a 4 KB B (8 x 8 x 8) halves the window misses but costs more than
@@ -661,50 +675,80 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
     unsigned long long miss_m = 0ull;
     int own_slot = 0, own_node = 0;          // CBET = 4: the ray's own node, in box A's component tiles / in the grid
     // Eight sums to the lane's eight nodes X0..Z1 in LDS.  slot = (x & XM) * XS + (y & YM) * YS + zr with the masks and
-    // strides of the lane's tile (byte offsets throughout: 24-bit multiplies by the byte strides, one three-operand
-    // add per node); zr = the z index, rotated by 7 x + 3 y in box A (Tile::zr).
+    // strides of the lane's tile (byte offsets throughout); zr = the z index, swizzled by x and y in box A (Tile::zr).
     auto lds_add8 = [&](const double *w) {
-        auto add8 = [&](int xm, int ym, int zm, int xs, int ys, int off, int rot) {
-            const int xa = X0 & xm, xb = X1 & xm, ya = Y0 & ym, yb = Y1 & ym;
-            const int x0 = __mul24(xa, xs * 8) + off * 8, x1 = __mul24(xb, xs * 8) + off * 8;
-            const int y0 = __mul24(ya, ys * 8), y1 = __mul24(yb, ys * 8);
-            const int ra = 7 * xa * rot, rb = 7 * xb * rot, sa = 3 * ya * rot, sb = 3 * yb * rot;
-            auto zb = [&](int z, int r) { return ((z + r) & zm) * 8; };
-            auto add = [&](int byte, double v) {
-                if (CBET_AUDIT(a, (unsigned)byte < (unsigned)NSLOT * 8u))
-                    __hip_atomic_fetch_add(static_cast<double *>(__builtin_assume_aligned(reinterpret_cast<char *>(s_val) + byte, 8)),
-                                           v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            };
-            if constexpr (T::ROT) {
-                // both boxes are dense with power-of-two strides here: x, y and the z index are disjoint bit fields of the
-                // byte offset, so a node's offset is (z term & mask) | (x | y) -- one v_and_or_b32 behind the z sum
-                const int xy00 = x0 | y0, xy10 = x1 | y0, xy01 = x0 | y1, xy11 = x1 | y1, zm8 = zm * 8;
-                auto at = [&](int xy, int z, int r) { return (((z + r) * 8) & zm8) | xy; };
-                add(at(xy00, Z0, ra + sa), w[0]);
-                add(at(xy10, Z0, rb + sa), w[1]);
-                add(at(xy00, Z1, ra + sa), w[2]);
-                add(at(xy10, Z1, rb + sa), w[3]);
-                add(at(xy01, Z0, ra + sb), w[4]);
-                add(at(xy11, Z0, rb + sb), w[5]);
-                add(at(xy01, Z1, ra + sb), w[6]);
-                add(at(xy11, Z1, rb + sb), w[7]);
-            } else {
-                add(add3(x0, y0, zb(Z0, ra + sa)), w[0]);
-                add(add3(x1, y0, zb(Z0, rb + sa)), w[1]);
-                add(add3(x0, y0, zb(Z1, ra + sa)), w[2]);
-                add(add3(x1, y0, zb(Z1, rb + sa)), w[3]);
-                add(add3(x0, y1, zb(Z0, ra + sb)), w[4]);
-                add(add3(x1, y1, zb(Z0, rb + sb)), w[5]);
-                add(add3(x0, y1, zb(Z1, ra + sb)), w[6]);
-                add(add3(x1, y1, zb(Z1, rb + sb)), w[7]);
-            }
+        auto add = [&](int byte, double v) {
+            if (CBET_AUDIT(a, (unsigned)byte < (unsigned)NSLOT * 8u))
+                __hip_atomic_fetch_add(static_cast<double *>(__builtin_assume_aligned(reinterpret_cast<char *>(s_val) + byte, 8)),
+                                       v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         };
-        if (b_active == 0) {   // scalar branch: everything goes to box A, compile-time masks and strides
-            add8(T::XM, T::YM, T::ZM, T::XS, T::YS, 0, T::ROT ? 1 : 0);
+        if constexpr (T::XOR) {
+            // Both boxes are dense with power-of-two strides here: x, y and the z index are disjoint bit fields of the byte
+            // offset, and box A's swizzle is an exclusive-or of an x and a y term into the z field -- a node's offset is the
+            // exclusive-or of a per-x, a per-y and a per-z term: one v_bitop3_b32 (truth table 0x96) per node.
+            int ax0, ax1, by0, by1, cz0, cz1;
+            if (b_active == 0) {   // scalar branch: everything goes to box A, compile-time masks and strides
+                ax0 = T::xterm(X0 & T::XM); ax1 = T::xterm(X1 & T::XM);
+                by0 = T::yterm(Y0 & T::YM); by1 = T::yterm(Y1 & T::YM);
+                cz0 = (Z0 & T::ZM) << 3; cz1 = (Z1 & T::ZM) << 3;
+            } else {               // a lane of box B: the plain dense 4 x 8 x 8 tile behind box A (tile_off, in doubles)
+                const bool toB = tile_off != 0;
+                const int xm = toB ? TB::XM : T::XM, zm = toB ? TB::ZM : T::ZM;
+                const int xmul = toB ? TB::XS * 8 : T::XS * 8 + 32, ymul = toB ? TB::YS * 8 : T::YS * 8 + 16;
+                const int keep = toB ? ~0 : ~0x80, off8 = tile_off * 8;
+                static_assert(TB::YM == T::YM, "one y mask for both boxes");
+                ax0 = (__mul24(X0 & xm, xmul) & keep) | off8; ax1 = (__mul24(X1 & xm, xmul) & keep) | off8;
+                by0 = __mul24(Y0 & T::YM, ymul); by1 = __mul24(Y1 & T::YM, ymul);
+                cz0 = (Z0 & zm) << 3; cz1 = (Z1 & zm) << 3;
+            }
+            auto at = [](int ax, int by, int cz) { return (int)__builtin_amdgcn_bitop3_b32(ax, by, cz, 0x96); };
+            add(at(ax0, by0, cz0), w[0]);
+            add(at(ax1, by0, cz0), w[1]);
+            add(at(ax0, by0, cz1), w[2]);
+            add(at(ax1, by0, cz1), w[3]);
+            add(at(ax0, by1, cz0), w[4]);
+            add(at(ax1, by1, cz0), w[5]);
+            add(at(ax0, by1, cz1), w[6]);
+            add(at(ax1, by1, cz1), w[7]);
         } else {
-            const bool toB = tile_off != 0;
-            add8(toB ? TB::XM : T::XM, toB ? TB::YM : T::YM, toB ? TB::ZM : T::ZM, toB ? TB::XS : T::XS,
-                 toB ? TB::YS : T::YS, tile_off, (T::ROT && !toB) ? 1 : 0);
+            // 24-bit multiplies by the byte strides; rot = 1: the z index rotated by 7 x + 3 y (box A of the CBET kernels)
+            auto add8 = [&](int xm, int ym, int zm, int xs, int ys, int off, int rot) {
+                const int xa = X0 & xm, xb = X1 & xm, ya = Y0 & ym, yb = Y1 & ym;
+                const int x0 = __mul24(xa, xs * 8) + off * 8, x1 = __mul24(xb, xs * 8) + off * 8;
+                const int y0 = __mul24(ya, ys * 8), y1 = __mul24(yb, ys * 8);
+                const int ra = 7 * xa * rot, rb = 7 * xb * rot, sa = 3 * ya * rot, sb = 3 * yb * rot;
+                auto zb = [&](int z, int r) { return ((z + r) & zm) * 8; };
+                if constexpr (T::ROT) {
+                    // both boxes are dense with power-of-two strides here: x, y and the z index are disjoint bit fields of the
+                    // byte offset, so a node's offset is (z term & mask) | (x | y) -- one v_and_or_b32 behind the z sum
+                    const int xy00 = x0 | y0, xy10 = x1 | y0, xy01 = x0 | y1, xy11 = x1 | y1, zm8 = zm * 8;
+                    auto at = [&](int xy, int z, int r) { return (((z + r) * 8) & zm8) | xy; };
+                    add(at(xy00, Z0, ra + sa), w[0]);
+                    add(at(xy10, Z0, rb + sa), w[1]);
+                    add(at(xy00, Z1, ra + sa), w[2]);
+                    add(at(xy10, Z1, rb + sa), w[3]);
+                    add(at(xy01, Z0, ra + sb), w[4]);
+                    add(at(xy11, Z0, rb + sb), w[5]);
+                    add(at(xy01, Z1, ra + sb), w[6]);
+                    add(at(xy11, Z1, rb + sb), w[7]);
+                } else {
+                    add(add3(x0, y0, zb(Z0, ra + sa)), w[0]);
+                    add(add3(x1, y0, zb(Z0, rb + sa)), w[1]);
+                    add(add3(x0, y0, zb(Z1, ra + sa)), w[2]);
+                    add(add3(x1, y0, zb(Z1, rb + sa)), w[3]);
+                    add(add3(x0, y1, zb(Z0, ra + sb)), w[4]);
+                    add(add3(x1, y1, zb(Z0, rb + sb)), w[5]);
+                    add(add3(x0, y1, zb(Z1, ra + sb)), w[6]);
+                    add(add3(x1, y1, zb(Z1, rb + sb)), w[7]);
+                }
+            };
+            if (b_active == 0) {   // scalar branch: everything goes to box A, compile-time masks and strides
+                add8(T::XM, T::YM, T::ZM, T::XS, T::YS, 0, T::ROT ? 1 : 0);
+            } else {
+                const bool toB = tile_off != 0;
+                add8(toB ? TB::XM : T::XM, toB ? TB::YM : T::YM, toB ? TB::ZM : T::ZM, toB ? TB::XS : T::XS,
+                     toB ? TB::YS : T::YS, tile_off, (T::ROT && !toB) ? 1 : 0);
+            }
         }
     };
     // eight values to the lane's eight nodes X0..Z1 in HBM (a lane outside both boxes)

@@ -26,6 +26,7 @@ ap.add_argument("--n", type=int, default=256)
 ap.add_argument("--bundles", type=int, default=10)
 ap.add_argument("--pads", default="", help="extra padded layouts to score: XS/YS pairs, e.g. 141/17,143/18")
 ap.add_argument("--accumulate", action="store_true", help="deposits summed in registers until the ray's nodes change")
+ap.add_argument("--xorsep", action="store_true", help="score every separable xor swizzle z ^ (a x & 15) ^ (b y & 15) (shipped mapping only)")
 args = ap.parse_args()
 CB = 2.0
 bn, r, ne, te = load_inputs()
@@ -81,7 +82,8 @@ LAYOUTS = {
     "dense xor f=(2x)^(5y)": lambda X, Y, Z: ((Z & 15) ^ ((2 * (X & 7)) ^ ((5 * (Y & 7)) & 15))),
     "dense xor f=x^(2y) ": lambda X, Y, Z: ((Z & 15) ^ ((X & 7) ^ (2 * (Y & 7)))),
     "dense xor f=(2x+1)... x*2^y": lambda X, Y, Z: ((Z & 15) ^ ((2 * (X & 7)) ^ (Y & 7))),
-    "dense add f=3x+7y (rotate z)": lambda X, Y, Z: (((Z & 15) + 7 * (X & 7) + 3 * (Y & 7)) & 15),
+    "dense add f=3x+7y (rotate z)": lambda X, Y, Z: (((Z & 15) + 7 * (X & 7) + 3 * (Y & 7)) & 15),     # the CBET kernels' box A
+    "dense xor 4x ^ 2y (shipped, plain trace)": lambda X, Y, Z: ((Z & 15) ^ ((4 * (X & 7)) & 15) ^ (2 * (Y & 7))),
     "dense add f=5x+3y": lambda X, Y, Z: (((Z & 15) + 5 * (X & 7) + 3 * (Y & 7)) & 15),
     "dense add f=4x+2y": lambda X, Y, Z: (((Z & 15) + 4 * (X & 7) + 2 * (Y & 7)) & 15),
     "dense add f=8x+4y": lambda X, Y, Z: (((Z & 15) + 8 * (X & 7) + 4 * (Y & 7)) & 15),
@@ -97,7 +99,12 @@ for _pair in [q for q in args.pads.split(",") if q]:
     _xs, _ys = (int(v) for v in _pair.split("/"))
     assert _xs >= 7 * _ys + 16, "rows overlap"
     LAYOUTS["pad %d/%d" % (_xs, _ys)] = (lambda xs, ys: (lambda X, Y, Z: ((X & 7) * xs + (Y & 7) * ys + (Z & 15)) & 15))(_xs, _ys)
-if args.pads:
+if args.xorsep:
+    LAYOUTS = {k: v for k, v in LAYOUTS.items() if "rotate z" in k or "ideal" in k}
+    for _a in range(16):
+        for _b in range(16):
+            LAYOUTS["xor sep a=%d b=%d" % (_a, _b)] = (lambda a_, b_: (lambda X, Y, Z: (Z & 15) ^ ((a_ * (X & 7)) & 15) ^ ((b_ * (Y & 7)) & 15)))(_a, _b)
+if args.pads or args.xorsep:
     MAPPINGS = {k: v for k, v in MAPPINGS.items() if "shipped" in k}
 
 
