@@ -24,7 +24,7 @@
 //     MI355X_MICROARCH.md "Global float atomics").  A second box adopts lanes that leave the first
 //     (bundles fan out after the turning point).  Corner order is lane-dependent so that rays sharing all
 //     8 nodes hit different LDS addresses in any one ds_add_f64; the first box stores its rows densely
-//     with a rotated z index, which spreads a bundle's nodes over the banks in 8 KB: with the second box
+//     with a swizzled z index (Tile::zr), which spreads a bundle's nodes over the banks in 8 KB: with the second box
 //     10,240 B per wave, 16 waves per CU.
 //   * control: every lane predicate that steers the step is a 64-bit mask in scalar registers (live rays, box B's lanes,
 //     lanes outside both boxes, who moved, who flushes), combined with scalar instructions and turned into a lane
