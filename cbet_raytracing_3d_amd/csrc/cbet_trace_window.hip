@@ -119,19 +119,36 @@ struct WaveCounters {
 #endif
 };
 
+// The deposit grid as the write-back paths see it.  W32: the grid is smaller than 2^32 bytes (checked on the host,
+// launch_trace_window), so a node's byte offset fits the 32-bit offset register of the scalar-base addressing mode -- one
+// v_add_lshl_u32 in front of the atomic instead of an add, a sign extension and a 64-bit shift-add.
+template <bool W32>
+struct Grid {
+    double *p;
+};
+template <bool W32>
+__device__ __forceinline__ void grid_add(const TraceArgs &a, Grid<W32> g, int node, double v)
+{
+    if constexpr (W32) global_add(a, reinterpret_cast<double *>(reinterpret_cast<char *>(g.p) + ((unsigned)node * 8u)), v);
+    else global_add(a, &g.p[node], v);
+}
+// ... at a 64-bit index (the components of the field pass lie whole per-beam arrays apart)
+template <bool W32>
+__device__ __forceinline__ void grid_add_far(const TraceArgs &a, Grid<W32> g, long index, double v) { global_add(a, &g.p[index], v); }
+
 // Take the plane `coord` (absolute, inside the box) of axis AX (0: x, 1: y) out of a tile: read the sums, zero the
 // non-zero ones and add them to HBM.  A plane is W x WZ entries (W = the other lateral extent), z fastest across
 // lanes, so one wave instruction covers whole rows -- 64-B lines when the z origin is brick-aligned.  Every vector
 // memory instruction that is really issued (some lane has a non-zero sum) is counted in wc.pend: the step's wait
 // for its record gather skips exactly that many younger instructions (see the kernel).
-template <class T, int AX, int NC>
+template <class T, int AX, int NC, class G>
 __device__ __forceinline__ void retire_plane(const TraceArgs &a, double *tile, const Origin &o, int coord, int lane,
-                                             double *edep, int sXh, int sYh, WaveCounters &wc, int coff, long gstride);
+                                             G edep, int sXh, int sYh, WaveCounters &wc, int coff, long gstride);
 
 // COUNT neighbouring planes (coord, coord + step, ...) of a single-component tile at once: all reads first, one wait.
-template <class T, int AX, int COUNT>
+template <class T, int AX, int COUNT, class G>
 __device__ __forceinline__ void retire_planes(const TraceArgs &a, double *tile, const Origin &o, int coord, int step,
-                                              int lane, double *edep, int sXh, int sYh, WaveCounters &wc)
+                                              int lane, G edep, int sXh, int sYh, WaveCounters &wc)
 {
     constexpr int WO = AX == 0 ? T::WY : T::WX;
     constexpr int IT = (WO * T::WZ + kWave - 1) / kWave;
@@ -162,14 +179,14 @@ __device__ __forceinline__ void retire_planes(const TraceArgs &a, double *tile, 
         if (v[q] != 0.0) {
             tile[slot[q]] = 0.0;
             ++wc.n_atomics;
-            global_add(a, &edep[node[q]], v[q]);
+            grid_add(a, edep, node[q], v[q]);
         }
     }
 }
 
-template <class T, int AX, int NC>
+template <class T, int AX, int NC, class G>
 __device__ __forceinline__ void retire_plane(const TraceArgs &a, double *tile, const Origin &o, int coord, int lane,
-                                             double *edep, int sXh, int sYh, WaveCounters &wc, int coff, long gstride)
+                                             G edep, int sXh, int sYh, WaveCounters &wc, int coff, long gstride)
 {
     constexpr int WO = AX == 0 ? T::WY : T::WX;      // extent of the other lateral axis
     constexpr int IT = (WO * T::WZ + kWave - 1) / kWave;
@@ -198,7 +215,7 @@ __device__ __forceinline__ void retire_plane(const TraceArgs &a, double *tile, c
                 const double vq = ok ? tile[coff + (q - 1) * T::DT + slot_d] : 0.0;
                 wc.pend += (CBET_BALLOT(vq != 0.0) != 0ull) ? 1 : 0;
                 if (vq != 0.0) {
-                    global_add(a, &edep[q * gstride + node], vq);
+                    grid_add_far(a, edep, q * gstride + node, vq);
                     tile[coff + (q - 1) * T::DT + slot_d] = 0.0;
                     ++wc.n_atomics;
                 }
@@ -208,16 +225,16 @@ __device__ __forceinline__ void retire_plane(const TraceArgs &a, double *tile, c
         if (v != 0.0) {  // only nodes that received deposits are non-zero, hence valid
             tile[slot] = 0.0;
             ++wc.n_atomics;
-            global_add(a, &edep[node], v);
+            grid_add(a, edep, node, v);
         }
     }
 }
 
 // z, single planes (tiles without bricks): the plane is WX x WY (x, y) entries, at most one per lane, each in its
 // own 64-B line of HBM.
-template <class T, int NC>
+template <class T, int NC, class G>
 __device__ __forceinline__ void retire_zplane(const TraceArgs &a, double *tile, const Origin &o, int coord, int lane,
-                                              double *edep, int sXh, int sYh, WaveCounters &wc, int coff, long gstride)
+                                              G edep, int sXh, int sYh, WaveCounters &wc, int coff, long gstride)
 {
     static_assert(T::WX * T::WY <= kWave, "one z-plane entry per lane");
     const int r0 = lane / T::WY, r1 = lane & T::YM, fixed = coord & T::ZM;
@@ -232,7 +249,7 @@ __device__ __forceinline__ void retire_zplane(const TraceArgs &a, double *tile, 
             const double vq = ok ? tile[coff + (q - 1) * T::DT + slot_d] : 0.0;
             wc.pend += (CBET_BALLOT(vq != 0.0) != 0ull) ? 1 : 0;
             if (vq != 0.0) {
-                global_add(a, &edep[q * gstride + node], vq);
+                grid_add_far(a, edep, q * gstride + node, vq);
                 tile[coff + (q - 1) * T::DT + slot_d] = 0.0;
                 ++wc.n_atomics;
             }
@@ -242,15 +259,15 @@ __device__ __forceinline__ void retire_zplane(const TraceArgs &a, double *tile, 
     if (v != 0.0) {
         tile[slot] = 0.0;
         ++wc.n_atomics;
-        global_add(a, &edep[node], v);
+        grid_add(a, edep, node, v);
     }
 }
 
 // z, bricks (WZ = 16): the 8 planes [zb, zb + 8), zb a multiple of 8, leave together.  One wave instruction per
 // tile x index; lanes = (y, z), z fastest: every atomic request is one full 64-B line of HBM.
-template <class T>
+template <class T, class G>
 __device__ __forceinline__ void retire_zbrick(const TraceArgs &a, double *tile, const Origin &o, int zb, int lane,
-                                              double *edep, int sXh, int sYh, WaveCounters &wc)
+                                              G edep, int sXh, int sYh, WaveCounters &wc)
 {
     static_assert(T::WY == 8 && T::WZ == 16, "a brick is 8 rows of 8 planes per tile x index");
     const int ty = lane >> 3, kz = lane & 7;
@@ -274,15 +291,15 @@ __device__ __forceinline__ void retire_zbrick(const TraceArgs &a, double *tile, 
             if (v[q] != 0.0) {
                 tile[slot[q]] = 0.0;
                 ++wc.n_atomics;
-                global_add(a, &edep[abs_in<T::XM>(o.x, t0 + q) * sXh + base_node], v[q]);
+                grid_add(a, edep, abs_in<T::XM>(o.x, t0 + q) * sXh + base_node, v[q]);
             }
         }
     }
 }
 
 // Everything a box still holds goes to HBM (wave end, or box B emptying).
-template <class T, int NC>
-__device__ __forceinline__ void flush_box(const TraceArgs &a, double *tile, const Origin &o, int lane, double *edep,
+template <class T, int NC, class G>
+__device__ __forceinline__ void flush_box(const TraceArgs &a, double *tile, const Origin &o, int lane, G edep,
                                           int sXh, int sYh, WaveCounters &wc, int coff, long gstride)
 {
     for (int t = 0; t < T::WX; ++t)
@@ -331,9 +348,9 @@ __device__ __forceinline__ int follow_brick_axis(int r, unsigned long long mm)
 // that count for this box.  The decisions are taken first, as scalars; the planes that leave are then written
 // back and the origin is moved by plain scalar arithmetic outside every divergent region (so that it stays in
 // scalar registers).  Returns true when the origin moved.
-template <class T, int NC>
+template <class T, int NC, class G>
 __device__ __forceinline__ bool follow_box(const TraceArgs &a, double *tile, Origin &o, unsigned long long mm, int lx,
-                                           int ly, int lz, int lane, double *edep, int sXh, int sYh, WaveCounters &wc,
+                                           int ly, int lz, int lane, G edep, int sXh, int sYh, WaveCounters &wc,
                                            int coff, long gstride)
 {
     auto leave = [&](auto axis, int d, int lo, int hi) {   // planes [lo, lo + |d|) or (hi - |d|, hi] leave along this axis
@@ -576,7 +593,7 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
     if (!work_item(a, blockIdx.x, beam, patch)) return;
     // beam-resolved deposition (cbet_params.per_beam_grids): beam b accumulates into its own grid,
     // edep[b * grid_stride ...]; otherwise every beam adds into the one grid (grid_stride = 0)
-    double *const edep = a.edep + (long)(beam - a.grid_beam0) * a.grid_stride;
+    const Grid<!IDX64> edep{a.edep + (long)(beam - a.grid_beam0) * a.grid_stride};
     const bool absorb = GENERIC ? (a.absorption == 1) : true;   // def.cuh:118
 
     Ray s = {};   // holes and culled rays keep zeros: their lanes run the arithmetic below on harmless values
@@ -754,14 +771,14 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
     // eight values to the lane's eight nodes X0..Z1 in HBM (a lane outside both boxes)
     auto hbm_add8 = [&](const double *w) {
         const int nX0 = __mul24(X0, sXh), nX1 = __mul24(X1, sXh), nY0 = __mul24(Y0, sYh), nY1 = __mul24(Y1, sYh);
-        global_add(a, &edep[nX0 + nY0 + Z0], w[0]);
-        global_add(a, &edep[nX1 + nY0 + Z0], w[1]);
-        global_add(a, &edep[nX0 + nY0 + Z1], w[2]);
-        global_add(a, &edep[nX1 + nY0 + Z1], w[3]);
-        global_add(a, &edep[nX0 + nY1 + Z0], w[4]);
-        global_add(a, &edep[nX1 + nY1 + Z0], w[5]);
-        global_add(a, &edep[nX0 + nY1 + Z1], w[6]);
-        global_add(a, &edep[nX1 + nY1 + Z1], w[7]);
+        grid_add(a, edep, nX0 + nY0 + Z0, w[0]);
+        grid_add(a, edep, nX1 + nY0 + Z0, w[1]);
+        grid_add(a, edep, nX0 + nY0 + Z1, w[2]);
+        grid_add(a, edep, nX1 + nY0 + Z1, w[3]);
+        grid_add(a, edep, nX0 + nY1 + Z0, w[4]);
+        grid_add(a, edep, nX1 + nY1 + Z0, w[5]);
+        grid_add(a, edep, nX0 + nY1 + Z1, w[6]);
+        grid_add(a, edep, nX1 + nY1 + Z1, w[7]);
         wc.n_atomics += 8;
     };
 
@@ -807,9 +824,9 @@ __global__ void __launch_bounds__(kWave, (CBET == 4) ? 1 : 4) k_trace_window(con
                     __hip_atomic_fetch_add(&s_val[own_slot + 2 * T::DT], q3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             } else if (inbox || CBET_LANES(hbm_m)) {
-                global_add(a, &edep[a.comp_stride + own_node], q1);
-                global_add(a, &edep[2 * a.comp_stride + own_node], q2);
-                global_add(a, &edep[3 * a.comp_stride + own_node], q3);
+                grid_add_far(a, edep, a.comp_stride + own_node, q1);
+                grid_add_far(a, edep, 2 * a.comp_stride + own_node, q2);
+                grid_add_far(a, edep, 3 * a.comp_stride + own_node, q3);
                 wc.n_atomics += 3;
             }
         }
@@ -1221,9 +1238,12 @@ hipError_t launch_trace_window(const TraceArgs &a, bool force_idx64, hipStream_t
     const long waves = a.item_count;
     if (waves <= 0) return hipSuccess;
     const dim3 grid((unsigned)waves), block(kWave);
-    // GENERIC is needed for bookkeeping mode, for step-record tables beyond 2^32 bytes (more than 2^27 nodes) and,
-    // with the CBET hooks, for gain grids of >= 2^32 bytes (32-bit byte offsets otherwise)
+    // GENERIC is needed for bookkeeping mode, for step-record tables beyond 2^32 bytes (more than 2^27 nodes), for deposit
+    // grids of >= 2^32 bytes (a beam's, with the caller's row pitch) and, with the CBET hooks, for gain grids of that size
+    // (32-bit byte offsets otherwise)
+    const unsigned long long grid_bytes = 8ull * (unsigned long long)a.sXh * (unsigned long long)(a.nx + 2);
     const bool generic = force_idx64 || (a.gain && 8ull * (unsigned long long)a.hsize >= (1ull << 32)) || a.absorption != 1 ||
+                         grid_bytes >= (1ull << 32) ||
                          sizeof(StepRecord) * (unsigned long long)a.nx * a.ny * a.nz > (1ull << 32);
     auto go = [&](auto wz, auto cbet) {
         constexpr int WZ = decltype(wz)::value, CB = decltype(cbet)::value;

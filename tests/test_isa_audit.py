@@ -86,11 +86,12 @@ def test_in_flight_record_is_never_moved(listing):
 
 def test_every_write_back_atomic_is_counted():
     """record_wait(vmcnt(N <= pend)) is only right while every vector-memory instruction issued after a gather is
-    counted in WaveCounters::pend: every global_add call site of the shipped kernel sits behind a `wc.pend +=` of its
+    counted in WaveCounters::pend: every global_add / grid_add call site of the shipped kernel sits behind a `wc.pend +=` of its
     own (the four-component field pass waits with vmcnt(0) and is exempt).  The file refuses targets other than gfx950
     (one in-order vmcnt shared by loads, stores and atomics)."""
     src = open(os.path.join(CSRC, "cbet_trace_window.hip")).read().splitlines()
-    sites = [i for i, l in enumerate(src) if "global_add(a," in l and "__device__" not in l]
+    # (grid_add / grid_add_far: global_add through the grid handle; their own bodies -- `g.p` -- are not call sites)
+    sites = [i for i, l in enumerate(src) if re.search(r"\b(global_add|grid_add|grid_add_far)\(a,", l) and "__device__" not in l and "g.p" not in l]
     assert len(sites) >= 12
     helper = [i for i, l in enumerate(src) if "auto hbm_add8 = " in l]          # eight adds of a lane outside both boxes:
     assert len(helper) == 1                                                      # counted where the helper is CALLED
