@@ -242,7 +242,8 @@ def roofline(prof, steps_per_launch, kernel_s, tot, steps_total):
                                                  "SQ_ACTIVE_INST_ANY_per_launch", "wave_steps_per_launch")) else None),
         "formula": "frac = SQ_INSTS_VALU / kernel_s / (1024 SIMDs x 2.4 GHz / 4); secondary.frac = TCC_EA0_ATOMIC x 64 B / "
                    "kernel_s / 1.3 TB/s; hbm_measured_frac = (2 x FETCH_SIZE + WRITE_SIZE) x 1 KiB / kernel_s / 8 TB/s (FETCH_SIZE tallies 128-B line requests at 64 B on gfx950: calibrated, profiles/r2/fetch_calibration.log)",
-        "note": "bound = vector-instruction issue (PMC: VALU busy the largest share of SIMD cycles); the algorithmic "
+        "note": "bound = vector-instruction issue, with the memory-side atomic unit level with it since round 5's last kernel "
+                "(valu_busy_frac against secondary.frac: whichever is larger binds, both are within a few percent); the algorithmic "
                 "128 B/ray-step figure is kept as algorithmic_GBps for context -- it exceeds the HBM peak because gathers "
                 "hit L2/MALL and scatters are combined in LDS (DESIGN.md 4.3)"})
     return out
